@@ -1,0 +1,208 @@
+"""ctypes loader for the CPU oracle (oracle/libcheetah_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by cheetah_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcheetah_oracle.so")
+
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "cheetah_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(os.path.join(_HERE, "cheetah_oracle.h"))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libcheetah_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    sig = {
+        "ora_fp_add": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "ora_fp_sub": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "ora_fp_neg": (C.c_uint64, [C.c_uint64]),
+        "ora_fp_double": (C.c_uint64, [C.c_uint64]),
+        "ora_fp_triple": (C.c_uint64, [C.c_uint64]),
+        "ora_fp_mul": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "ora_fp_square": (C.c_uint64, [C.c_uint64]),
+        "ora_fp_mul_by_u32": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+        "ora_fp_canonical": (C.c_uint64, [C.c_uint64]),
+        "ora_fp_invert": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint64)]),
+        "ora_reduce_u128": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "ora_reduce_u96": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+        "ora_fp6_add": (None, [u64p, u64p, u64p]),
+        "ora_fp6_sub": (None, [u64p, u64p, u64p]),
+        "ora_fp6_neg": (None, [u64p, u64p]),
+        "ora_fp6_double": (None, [u64p, u64p]),
+        "ora_fp6_triple": (None, [u64p, u64p]),
+        "ora_fp6_mul": (None, [u64p, u64p, u64p]),
+        "ora_fp6_square": (None, [u64p, u64p]),
+        "ora_fp6_mul_by_u32": (None, [u64p, C.c_uint32, u64p]),
+        "ora_fp6_mul_by_fp": (None, [u64p, C.c_uint64, u64p]),
+        "ora_fp6_frobenius": (None, [u64p, u64p]),
+        "ora_fp6_frobenius_double": (None, [u64p, u64p]),
+        "ora_fp6_frobenius_triple": (None, [u64p, u64p]),
+        "ora_fp6_invert": (C.c_int, [u64p, u64p]),
+        "ora_fp6_canonical": (None, [u64p, u64p]),
+        "ora_fp6_is_zero": (C.c_int, [u64p]),
+        "ora_mul_by_3b": (None, [u64p, u64p]),
+        "ora_bytes_to_radix_16": (None, [u8p, i8p]),
+        "ora_bytes_to_radix_256": (None, [u8p, i8p]),
+        "ora_bytes_to_wnaf_vartime": (None, [u8p, C.c_int, i8p]),
+        "ora_proj_double": (None, [u64p, u64p]),
+        "ora_proj_double_unchecked": (None, [u64p, u64p]),
+        "ora_proj_add": (None, [u64p, u64p, u64p]),
+        "ora_proj_add_mixed": (None, [u64p, u64p, C.c_uint8, u64p]),
+        "ora_proj_add_mixed_unchecked": (None, [u64p, u64p, C.c_uint8, u64p]),
+        "ora_proj_to_affine": (None, [u64p, u64p, u8p]),
+        "ora_proj_is_on_curve": (C.c_int, [u64p]),
+        "ora_jac_double": (None, [u64p, u64p]),
+        "ora_jac_double_unchecked": (None, [u64p, u64p]),
+        "ora_jac_add_mixed_unchecked": (None, [u64p, u64p, C.c_uint8, u64p]),
+        "ora_jac_to_affine": (None, [u64p, u64p, u8p]),
+        "ora_jac_is_on_curve": (C.c_int, [u64p]),
+        "ora_mjac_double_unchecked": (None, [u64p, u64p]),
+        "ora_mjac_add_mixed_unchecked": (None, [u64p, u64p, C.c_uint8, u64p]),
+        "ora_mjac_to_affine": (None, [u64p, u64p, u8p]),
+        "ora_proj_batch_normalize": (None, [u64p, C.c_size_t, u64p, u8p]),
+        "ora_jac_batch_normalize": (None, [u64p, C.c_size_t, u64p, u8p]),
+        "ora_lookup_table_from_proj": (None, [u64p, C.c_int, u64p, u8p]),
+        "ora_naf_table_from_proj": (None, [u64p, C.c_int, u64p, u8p]),
+        "ora_basepoint_table": (C.POINTER(C.c_uint64), []),
+        "ora_basepoint_lookup": (C.POINTER(C.c_uint64), []),
+        "ora_minus_shift_point_array": (C.POINTER(C.c_uint64), []),
+        "ora_shift_point_affine": (C.POINTER(C.c_uint64), []),
+        "ora_generator_affine": (C.POINTER(C.c_uint64), []),
+        "ora_proj_multiply": (None, [u64p, u8p, u64p]),
+        "ora_proj_multiply_vartime": (None, [u64p, u8p, u64p]),
+        "ora_basepoint_table_multiply": (None, [u8p, u64p]),
+        "ora_basepoint_lookup_multiply": (None, [u8p, u64p]),
+        "ora_jac_multiply": (None, [u64p, u8p, u64p]),
+        "ora_jac_multiply_vartime": (None, [u64p, u8p, u64p]),
+        "ora_num_threads": (C.c_int, []),
+        "ora_fp6_mul_batch": (None, [u64p, u64p, u64p, C.c_size_t]),
+        "ora_fp6_square_batch": (None, [u64p, u64p, C.c_size_t]),
+        "ora_fp6_invert_batch": (None, [u64p, u64p, u8p, C.c_size_t]),
+        "ora_mul_by_generator_batch": (None, [u8p, u64p, u8p, C.c_size_t, C.c_int]),
+        "ora_multiply_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
+        "ora_multiply_vartime_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
+        "ora_jac_batch_normalize_chunked": (None, [u64p, C.c_size_t, C.c_size_t, u64p, u8p]),
+        "ora_proj_batch_normalize_chunked": (None, [u64p, C.c_size_t, C.c_size_t, u64p, u8p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+# ---- numpy-friendly helpers -------------------------------------------------
+
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint8))
+
+
+def fp6_binop(name, a, b):
+    out = np.zeros(6, np.uint64)
+    getattr(lib(), name)(_u64(a), _u64(b), out)
+    return out
+
+
+def fp6_unop(name, a):
+    out = np.zeros(6, np.uint64)
+    getattr(lib(), name)(_u64(a), out)
+    return out
+
+
+def fp6_invert(a):
+    out = np.zeros(6, np.uint64)
+    ok = lib().ora_fp6_invert(_u64(a), out)
+    return (out if ok else None)
+
+
+def table(name, n_points):
+    ptr = getattr(lib(), name)()
+    return np.ctypeslib.as_array(ptr, shape=(n_points, 12)).copy()
+
+
+def canon(a):
+    return _u64(a) % np.uint64(0xFFFFFFFF00000001)
+
+
+def fp6_mul_batch(a, b):
+    a, b = _u64(a), _u64(b)
+    out = np.empty_like(a)
+    lib().ora_fp6_mul_batch(a, b, out, a.size // 6)
+    return out
+
+
+def fp6_square_batch(a):
+    a = _u64(a)
+    out = np.empty_like(a)
+    lib().ora_fp6_square_batch(a, out, a.size // 6)
+    return out
+
+
+def fp6_invert_batch(a):
+    a = _u64(a)
+    out = np.empty_like(a)
+    ok = np.empty(a.size // 6, np.uint8)
+    lib().ora_fp6_invert_batch(a, out, ok, a.size // 6)
+    return out, ok
+
+
+def _out_bufs(n, out_form):
+    w = 12 if out_form == 0 else 18
+    return np.empty((n, w), np.uint64), np.empty(n, np.uint8)
+
+
+def mul_by_generator_batch(scalars, out_form=0):
+    s = _u8(scalars).reshape(-1, 32)
+    out, inf = _out_bufs(len(s), out_form)
+    lib().ora_mul_by_generator_batch(s, out, inf, len(s), out_form)
+    return out, inf
+
+
+def multiply_batch(pts, in_form, scalars, out_form=0, vartime=False):
+    s = _u8(scalars).reshape(-1, 32)
+    p = _u64(pts).reshape(len(s), 12 if in_form == 0 else 18)
+    out, inf = _out_bufs(len(s), out_form)
+    f = lib().ora_multiply_vartime_batch if vartime else lib().ora_multiply_batch
+    f(p, in_form, s, out, inf, len(s), out_form)
+    return out, inf
+
+
+def batch_normalize(p, jacobian, chunk=0):
+    p = _u64(p).reshape(-1, 18)
+    n = len(p)
+    xy = np.empty((n, 12), np.uint64)
+    inf = np.empty(n, np.uint8)
+    f = lib().ora_jac_batch_normalize_chunked if jacobian else lib().ora_proj_batch_normalize_chunked
+    f(p, n, chunk, xy, inf)
+    return xy, inf
