@@ -1,0 +1,74 @@
+"""ctypes binding of the C ABI (include/cheetah_hip.h).
+
+The library is the product: if it cannot be loaded, or a call fails, this module
+raises -- there is no CPU fallback anywhere in cheetah_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcheetah_hip.so")
+
+AFFINE, PROJECTIVE, JACOBIAN = 0, 1, 2
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_SCALAR, ERR_NOMEM = -1, -2, -3, -4, -5
+
+# every symbol include/cheetah_hip.h declares: (restype, argtypes)
+_vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
+SIGNATURES = {
+    "cheetah_ctx_create": (C.c_int32, [_i, C.POINTER(_vp)]),
+    "cheetah_ctx_destroy": (C.c_int32, [_vp]),
+    "cheetah_ctx_set_stream": (C.c_int32, [_vp, _vp]),
+    "cheetah_ctx_use_own_stream": (C.c_int32, [_vp]),
+    "cheetah_ctx_synchronize": (C.c_int32, [_vp]),
+    "cheetah_last_error": (C.c_char_p, [_vp]),
+    "cheetah_version": (C.c_char_p, []),
+    "cheetah_fp6_mul_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_fp6_square_batch": (C.c_int32, [_vp, _vp, _vp, _sz]),
+    "cheetah_fp6_invert_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_fp6_mul_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_fp6_square_batch_dev": (C.c_int32, [_vp, _vp, _vp, _sz]),
+    "cheetah_fp6_invert_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_batch_normalize_projective": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_batch_normalize_jacobian": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_batch_normalize_projective_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_batch_normalize_jacobian_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_mul_by_generator_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_mul_by_generator_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_vartime_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_read_table": (C.c_int32, [_vp, _i, _vp, _sz]),
+    "cheetah_synth_fp6_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),
+    "cheetah_synth_scalars_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),
+    "cheetah_debug_op_dev": (C.c_int32, [_vp, _i, _vp, _vp, _vp, _sz]),
+    "cheetah_calibrate_mad_peak": (C.c_int32, [_vp, C.POINTER(C.c_double)]),
+    "cheetah_timer_start": (C.c_int32, [_vp]),
+    "cheetah_timer_stop_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class CheetahError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cheetah_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libcheetah_hip.so (built by `make -C cheetah_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP library missing: %s (run __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,511 @@
+// C ABI of the batched Cheetah engine (include/cheetah_hip.h).  Host side only:
+// argument checks, device buffers, kernel launches.  No CPU fallback exists: a
+// call either runs the HIP kernels or returns an error code.
+#include "../../include/cheetah_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "kernels.hip.h"
+
+using namespace cheetah;
+
+struct cheetah_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    DeviceTables* tables = nullptr;
+    u64* scratch = nullptr;
+    size_t scratch_words = 0;
+    int num_cus = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+static std::string g_create_err;
+static std::mutex g_err_mu;
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                \
+            return CHEETAH_ERR_HIP;                                                         \
+        }                                                                                   \
+    } while (0)
+
+static int32_t fail(cheetah_ctx* ctx, int32_t code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// Generator (src/curve/affine.rs:255-275) and shift point (src/constants.rs:43-61).
+static const u64 GENERATOR_XY[12] = {
+    0x263a588f4b0118a1ull, 0x7757a0bcb26a142dull, 0x9215adfc1e925890ull, 0x430aad2ce14759a4ull,
+    0x0534ece54de4b2c8ull, 0xb39050f01f7b1f33ull, 0xd57f0d0d47482534ull, 0x26821d894fa8ea0full,
+    0xc77f564783ef13a1ull, 0x949c360784284ec2ull, 0xb7040bd639ef3cc4ull, 0x8aa635f2719d255full};
+static const u64 SHIFT_XY[12] = {
+    0xab95fb0d188ff2b1ull, 0xf38263a8c954493eull, 0x1bc968d6739028b7ull, 0x4f67684fe6b27d1full,
+    0x6504f8bbba9077b4ull, 0x860838116d76e545ull, 0x56988918d5b02cf3ull, 0xc9fe3ef9d7652c54ull,
+    0x4923e90c4d6f4538ull, 0xc747ac3f82369f27ull, 0x6e74c106972c71f5ull, 0xcf190938f1c64bb5ull};
+
+extern "C" const char* cheetah_version(void) { return "cheetah-hip 0.1 (gfx950)"; }
+
+extern "C" const char* cheetah_last_error(const cheetah_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return g_create_err.c_str();
+}
+
+static int32_t create_fail(cheetah_ctx* ctx, int32_t code, const std::string& msg) {
+    {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        g_create_err = msg;
+    }
+    if (ctx) cheetah_ctx_destroy(ctx);
+    return code;
+}
+
+extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
+    if (!out) return create_fail(nullptr, CHEETAH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return create_fail(nullptr, CHEETAH_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= ndev) return create_fail(nullptr, CHEETAH_ERR_INVALID, "device_id out of range");
+    cheetah_ctx* ctx = new (std::nothrow) cheetah_ctx();
+    if (!ctx) return create_fail(nullptr, CHEETAH_ERR_NOMEM, "out of host memory");
+    ctx->device = device_id;
+#define CREATE_TRY(expr)                                                                             \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return create_fail(ctx, CHEETAH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return create_fail(ctx, CHEETAH_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    ctx->num_cus = prop.multiProcessorCount;
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    CREATE_TRY(hipEventCreate(&ctx->ev0));
+    CREATE_TRY(hipEventCreate(&ctx->ev1));
+    CREATE_TRY(hipMalloc(&ctx->tables, sizeof(DeviceTables)));
+    u64* seeds = nullptr;
+    CREATE_TRY(hipMalloc(&seeds, 24 * sizeof(u64)));
+    CREATE_TRY(hipMemcpyAsync(seeds, GENERATOR_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    CREATE_TRY(hipMemcpyAsync(seeds + 12, SHIFT_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(64), 0, ctx->stream, ctx->tables, seeds, seeds + 12);
+    CREATE_TRY(hipGetLastError());
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+    CREATE_TRY(hipFree(seeds));
+#undef CREATE_TRY
+    *out = ctx;
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_ctx_destroy(cheetah_ctx* ctx) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->tables) (void)hipFree(ctx->tables);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_ctx_set_stream(cheetah_ctx* ctx, void* hip_stream) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_ctx_use_own_stream(cheetah_ctx* ctx) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    ctx->stream = ctx->own_stream;
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_ctx_synchronize(cheetah_ctx* ctx) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+// Grid for the compute-bound per-lane kernels: enough 256-thread workgroups to
+// fill every CU at the occupancy the kernel's registers allow, no more than the
+// work needs.  The kernels grid-stride over the rest.
+static int lane_grid(const cheetah_ctx* ctx, size_t n_lanes_needed, int blocks_per_cu) {
+    size_t want = (n_lanes_needed + BLOCK - 1) / BLOCK;
+    size_t cap = (size_t)ctx->num_cus * blocks_per_cu;
+    size_t g = want < cap ? want : cap;
+    return g ? (int)g : 1;
+}
+
+static int32_t ensure_scratch(cheetah_ctx* ctx, size_t words) {
+    if (ctx->scratch_words >= words) return CHEETAH_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) HIP_TRY(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_words = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->scratch, words * sizeof(u64)));
+    ctx->scratch_words = words;
+    return CHEETAH_OK;
+}
+
+#define CHECK_CTX(ctx)                                   \
+    do {                                                 \
+        if (!(ctx)) return CHEETAH_ERR_INVALID;          \
+        HIP_TRY(ctx, hipSetDevice((ctx)->device));       \
+    } while (0)
+
+// ---------------------------------------------------------------- Fp6 -----
+
+template <int OP>
+static int32_t fp6_elementwise_dev(cheetah_ctx* ctx, const u64* a, const u64* b, u64* out, u8* is_some, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!a || !out || (OP == EW_MUL && !b)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned8(a) || !aligned8(out) || (b && !aligned8(b))) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    size_t tiles = (n + BLOCK - 1) / BLOCK;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    int grid = (int)(tiles < cap ? tiles : cap);
+    hipLaunchKernelGGL((k_fp6_elementwise<OP>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a, b, out, is_some, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_fp6_mul_batch_dev(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return fp6_elementwise_dev<EW_MUL>(ctx, a, b, out, nullptr, n);
+}
+extern "C" int32_t cheetah_fp6_square_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return fp6_elementwise_dev<EW_SQUARE>(ctx, a, nullptr, out, nullptr, n);
+}
+extern "C" int32_t cheetah_fp6_invert_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    return fp6_elementwise_dev<EW_INVERT>(ctx, a, nullptr, out, is_some, n);
+}
+
+// ------------------------------------------------------ batch_normalize -----
+
+template <int JAC>
+static int32_t batch_normalize_dev(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8* inf, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!xyz || !xy || !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned8(xyz) || !aligned8(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    constexpr int CHUNK = 8;
+    size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    int grid = lane_grid(ctx, nchunks, 8);
+    hipLaunchKernelGGL((k_batch_normalize<JAC, CHUNK>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_batch_normalize_projective_dev(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
+    return batch_normalize_dev<0>(ctx, xyz, xy, inf, n);
+}
+extern "C" int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
+    return batch_normalize_dev<1>(ctx, xyz, xy, inf, n);
+}
+
+// ------------------------------------------------------------- ladders -----
+
+static int32_t check_forms(cheetah_ctx* ctx, int in_form, int out_form) {
+    if (in_form != CHEETAH_AFFINE && in_form != CHEETAH_PROJECTIVE) return fail(ctx, CHEETAH_ERR_INVALID, "in_form must be AFFINE or PROJECTIVE");
+    if (out_form != CHEETAH_AFFINE && out_form != CHEETAH_PROJECTIVE) return fail(ctx, CHEETAH_ERR_INVALID, "out_form must be AFFINE or PROJECTIVE");
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const uint8_t* scalars32, uint64_t* out, uint8_t* inf,
+                                                      size_t n, int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    int grid = lane_grid(ctx, n, 2);
+    if (out_form == CHEETAH_AFFINE)
+        hipLaunchKernelGGL((k_mul_by_generator<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
+    else
+        hipLaunchKernelGGL((k_mul_by_generator<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+template <bool VARTIME>
+static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
+                            int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    int grid = lane_grid(ctx, n, 2);
+    if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
+#define LAUNCH(KERN, I, O) \
+    hipLaunchKernelGGL((KERN<I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts, scalars32, out, inf, n, ctx->scratch)
+    const int sel = (in_form == CHEETAH_PROJECTIVE ? 2 : 0) | (out_form == CHEETAH_PROJECTIVE ? 1 : 0);
+    if (VARTIME) {
+        switch (sel) {
+            case 0: LAUNCH(k_multiply_vartime, 0, 0); break;
+            case 1: LAUNCH(k_multiply_vartime, 0, 1); break;
+            case 2: LAUNCH(k_multiply_vartime, 1, 0); break;
+            default: LAUNCH(k_multiply_vartime, 1, 1); break;
+        }
+    } else {
+        switch (sel) {
+            case 0: LAUNCH(k_multiply_ct, 0, 0); break;
+            case 1: LAUNCH(k_multiply_ct, 0, 1); break;
+            case 2: LAUNCH(k_multiply_ct, 1, 0); break;
+            default: LAUNCH(k_multiply_ct, 1, 1); break;
+        }
+    }
+#undef LAUNCH
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_multiply_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
+                                              uint64_t* out, uint8_t* inf, size_t n, int out_form) {
+    return multiply_dev<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
+                                                      const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
+                                                      int out_form) {
+    return multiply_dev<true>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+}
+
+// ------------------------------------------------- host-pointer wrappers -----
+// Copy in, run the same device entry point, copy out.  PCIe-inclusive; the
+// `_dev` forms are what the benchmarks time.
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+}  // namespace
+
+#define H2D(ctx, dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (ctx)->stream))
+#define D2H(ctx, dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (ctx)->stream))
+
+extern "C" int32_t cheetah_fp6_mul_batch(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!a || !b || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf da, db, dout;
+    HIP_TRY(ctx, da.alloc(n * 48));
+    HIP_TRY(ctx, db.alloc(n * 48));
+    HIP_TRY(ctx, dout.alloc(n * 48));
+    H2D(ctx, da.p, a, n * 48);
+    H2D(ctx, db.p, b, n * 48);
+    if (int32_t rc = cheetah_fp6_mul_batch_dev(ctx, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n)) return rc;
+    D2H(ctx, out, dout.p, n * 48);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_fp6_square_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!a || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf da, dout;
+    HIP_TRY(ctx, da.alloc(n * 48));
+    HIP_TRY(ctx, dout.alloc(n * 48));
+    H2D(ctx, da.p, a, n * 48);
+    if (int32_t rc = cheetah_fp6_square_batch_dev(ctx, da.as<u64>(), dout.as<u64>(), n)) return rc;
+    D2H(ctx, out, dout.p, n * 48);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_fp6_invert_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!a || !out || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf da, dout, dsome;
+    HIP_TRY(ctx, da.alloc(n * 48));
+    HIP_TRY(ctx, dout.alloc(n * 48));
+    HIP_TRY(ctx, dsome.alloc(n));
+    H2D(ctx, da.p, a, n * 48);
+    if (int32_t rc = cheetah_fp6_invert_batch_dev(ctx, da.as<u64>(), dout.as<u64>(), dsome.as<u8>(), n)) return rc;
+    D2H(ctx, out, dout.p, n * 48);
+    D2H(ctx, is_some, dsome.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+template <int JAC>
+static int32_t batch_normalize_host(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8* inf, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!xyz || !xy || !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf din, dxy, dinf;
+    HIP_TRY(ctx, din.alloc(n * 144));
+    HIP_TRY(ctx, dxy.alloc(n * 96));
+    HIP_TRY(ctx, dinf.alloc(n));
+    H2D(ctx, din.p, xyz, n * 144);
+    if (int32_t rc = batch_normalize_dev<JAC>(ctx, din.as<u64>(), dxy.as<u64>(), dinf.as<u8>(), n)) return rc;
+    D2H(ctx, xy, dxy.p, n * 96);
+    D2H(ctx, inf, dinf.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_batch_normalize_projective(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
+    return batch_normalize_host<0>(ctx, xyz, xy, inf, n);
+}
+extern "C" int32_t cheetah_batch_normalize_jacobian(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
+    return batch_normalize_host<1>(ctx, xyz, xy, inf, n);
+}
+
+extern "C" int32_t cheetah_mul_by_generator_batch(cheetah_ctx* ctx, const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
+                                                  int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    for (size_t i = 0; i < n; i++)
+        if ((scalars32[32 * i + 31] >> 4) > 7)
+            return fail(ctx, CHEETAH_ERR_SCALAR, "scalar with top nibble > 7: outside BasePointTable's LookupTable<8> range");
+    const size_t w = out_form == CHEETAH_AFFINE ? 96 : 144;
+    DevBuf dsc, dout, dinf;
+    HIP_TRY(ctx, dsc.alloc(n * 32));
+    HIP_TRY(ctx, dout.alloc(n * w));
+    HIP_TRY(ctx, dinf.alloc(n));
+    H2D(ctx, dsc.p, scalars32, n * 32);
+    if (int32_t rc = cheetah_mul_by_generator_batch_dev(ctx, dsc.as<u8>(), dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
+    D2H(ctx, out, dout.p, n * w);
+    if (inf) D2H(ctx, inf, dinf.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+template <bool VARTIME>
+static int32_t multiply_host(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
+                             int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144, wo = out_form == CHEETAH_AFFINE ? 96 : 144;
+    DevBuf dp, dsc, dout, dinf;
+    HIP_TRY(ctx, dp.alloc(n * wi));
+    HIP_TRY(ctx, dsc.alloc(n * 32));
+    HIP_TRY(ctx, dout.alloc(n * wo));
+    HIP_TRY(ctx, dinf.alloc(n));
+    H2D(ctx, dp.p, pts, n * wi);
+    H2D(ctx, dsc.p, scalars32, n * 32);
+    if (int32_t rc = multiply_dev<VARTIME>(ctx, dp.as<u64>(), in_form, dsc.as<u8>(), dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
+    D2H(ctx, out, dout.p, n * wo);
+    if (inf) D2H(ctx, inf, dinf.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_multiply_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, uint64_t* out,
+                                          uint8_t* inf, size_t n, int out_form) {
+    return multiply_host<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_multiply_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
+                                                  uint64_t* out, uint8_t* inf, size_t n, int out_form) {
+    return multiply_host<true>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+}
+
+// ------------------------------------------------------- tables, synth -----
+
+extern "C" int32_t cheetah_read_table(cheetah_ctx* ctx, int which, uint64_t* out_xy, size_t max_points) {
+    CHECK_CTX(ctx);
+    if (!out_xy) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    const char* base = reinterpret_cast<const char*>(ctx->tables);
+    size_t off, pts;
+    if (which == 0) {
+        off = offsetof(DeviceTables, basepoint);
+        pts = 256;
+    } else if (which == 1) {
+        off = offsetof(DeviceTables, shift);
+        pts = 3;
+    } else {
+        return fail(ctx, CHEETAH_ERR_INVALID, "unknown table");
+    }
+    if (pts > max_points) pts = max_points;
+    HIP_TRY(ctx, hipMemcpyAsync(out_xy, base + off, pts * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_synth_fp6_dev(cheetah_ctx* ctx, uint64_t seed, uint64_t start, uint64_t* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!out || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
+    hipLaunchKernelGGL(k_synth_fp6, dim3(ctx->num_cus * 8), dim3(BLOCK), 0, ctx->stream, seed, start, out, n * 6);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_synth_scalars_dev(cheetah_ctx* ctx, uint64_t seed, uint64_t start, uint8_t* out32, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!out32 || !aligned8(out32)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
+    hipLaunchKernelGGL(k_synth_scalars, dim3(ctx->num_cus * 8), dim3(BLOCK), 0, ctx->stream, seed, start,
+                       reinterpret_cast<u64*>(out32), n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+// ---------------------------------------------------------- diagnostics -----
+
+extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!a || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    hipLaunchKernelGGL(k_debug_op, dim3(lane_grid(ctx, n, 4)), dim3(BLOCK), 0, ctx->stream, op, a, b, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_calibrate_mad_peak(cheetah_ctx* ctx, double* tera_mads_per_s) {
+    CHECK_CTX(ctx);
+    if (!tera_mads_per_s) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    u64* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, 64));
+    const int iters = 4096, blocks = ctx->num_cus * 8;
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(k_mad_peak, dim3(blocks), dim3(BLOCK), 0, ctx->stream, d, (u32)rep, iters);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    HIP_TRY(ctx, hipFree(d));
+    *tera_mads_per_s = (double)blocks * BLOCK * 64.0 * iters / (best * 1e-3) / 1e12;
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_timer_start(cheetah_ctx* ctx) {
+    CHECK_CTX(ctx);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_timer_stop_ms(cheetah_ctx* ctx, float* ms) {
+    CHECK_CTX(ctx);
+    if (!ms) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return CHEETAH_OK;
+}

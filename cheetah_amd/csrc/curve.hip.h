@@ -1,0 +1,259 @@
+// Cheetah curve E: y^2 = x^3 + x + (u + 395) over Fp6 -- point formulas.
+//
+// Every formula follows the reference's operation SEQUENCE (cited per function)
+// so that the projective / Jacobian representative (X:Y:Z) it produces is the
+// same element-for-element as the reference's, not only the affine point
+// (parity level L2 of SURVEY.md 8b).  The field operations underneath are this
+// build's own (fp.hip.h, fp6.hip.h).
+#pragma once
+#include "fp6.hip.h"
+
+namespace cheetah {
+
+struct Affine {  // src/curve/affine.rs:37-41
+    Fp6 x, y;
+    bool inf;
+};
+struct Proj {  // src/curve/projective.rs:76-80 (also used for Jacobian, src/curve/jacobian.rs:76-80)
+    Fp6 x, y, z;
+};
+struct MJac {  // src/curve/jacobian.rs:943-948
+    Fp6 x, y, z, z4;
+};
+
+CH_DEV Affine affine_identity() {  // src/curve/affine.rs:224-230
+    Affine a;
+    a.x = fp6_zero();
+    a.y = fp6_one();
+    a.inf = true;
+    return a;
+}
+CH_DEV Proj proj_identity() {  // src/curve/projective.rs:204-210
+    Proj p;
+    p.x = fp6_zero();
+    p.y = fp6_one();
+    p.z = fp6_zero();
+    return p;
+}
+CH_DEV Proj proj_from_affine(const Affine& a) {  // src/curve/projective.rs:102-110
+    Proj p;
+    p.x = a.x;
+    p.y = a.y;
+    p.z = a.inf ? fp6_zero() : fp6_one();
+    return p;
+}
+CH_DEV MJac mjac_from_affine(const Affine& a) {  // src/curve/jacobian.rs:970-979
+    MJac p;
+    p.x = a.x;
+    p.y = a.y;
+    p.z = a.inf ? fp6_zero() : fp6_one();
+    p.z4 = p.z;
+    return p;
+}
+// -a; the identity keeps y = 1.                     (src/curve/affine.rs:164-175)
+CH_DEV Affine affine_cond_neg(const Affine& a, bool negate) {
+    Affine r;
+    r.x = a.x;
+    r.y = fp6_select(a.y, fp6_select(fp6_neg(a.y), fp6_one(), a.inf), negate);
+    r.inf = a.inf;
+    return r;
+}
+
+// src/curve/projective.rs:400-443
+CH_DEV Proj proj_double_unchecked(const Proj& s) {
+    Fp6 x2 = fp6_square(s.x);
+    Fp6 z2 = fp6_square(s.z);
+    Fp6 a = fp6_double(x2);
+    a = fp6_add(a, x2);
+    a = fp6_add(a, z2);
+    Fp6 b = fp6_mul(s.y, s.z);
+    Fp6 t3 = fp6_mul(s.y, b);
+    Fp6 c = fp6_mul(t3, s.x);
+    Fp6 d = fp6_double(c);
+    Fp6 c4 = fp6_double(d);
+    d = fp6_double(c4);
+    Fp6 t = fp6_square(a);
+    d = fp6_sub(t, d);
+    Fp6 x3 = fp6_mul(b, d);
+    x3 = fp6_double(x3);
+    Fp6 y3 = fp6_sub(c4, d);
+    y3 = fp6_mul(a, y3);
+    t3 = fp6_double(t3);
+    t3 = fp6_square(t3);
+    t3 = fp6_double(t3);
+    y3 = fp6_sub(y3, t3);
+    Fp6 z3 = fp6_double(b);
+    z3 = fp6_square(z3);
+    z3 = fp6_mul(z3, b);
+    z3 = fp6_double(z3);
+    Proj r;
+    r.x = x3;
+    r.y = y3;
+    r.z = z3;
+    return r;
+}
+
+// src/curve/projective.rs:349-393 (same values as the unchecked form mod p:
+// 4c, 8c, 8 t3^2, 8 b^3; then the identity select)
+CH_DEV Proj proj_double(const Proj& s) {
+    Proj r = proj_double_unchecked(s);
+    if (fp6_is_zero(s.z)) r = proj_identity();
+    return r;
+}
+
+// Complete addition, Algorithm 1 of Renes-Costello-Batina 2015 as in
+// src/curve/projective.rs:456-515.
+CH_DEV Proj proj_add(const Proj& s, const Proj& r) {
+    Fp6 t0 = fp6_mul(s.x, r.x);
+    Fp6 t1 = fp6_mul(s.y, r.y);
+    Fp6 t2 = fp6_mul(s.z, r.z);
+    Fp6 t3 = fp6_add(s.x, s.y);
+    Fp6 t4 = fp6_add(r.x, r.y);
+    t3 = fp6_mul(t3, t4);
+    t4 = fp6_add(t0, t1);
+    t3 = fp6_sub(t3, t4);
+    t4 = fp6_add(s.x, s.z);
+    Fp6 t5 = fp6_add(r.x, r.z);
+    t4 = fp6_mul(t4, t5);
+    t5 = fp6_add(t0, t2);
+    t4 = fp6_sub(t4, t5);
+    t5 = fp6_add(s.y, s.z);
+    Fp6 x3 = fp6_add(r.y, r.z);
+    t5 = fp6_mul(t5, x3);
+    x3 = fp6_add(t1, t2);
+    t5 = fp6_sub(t5, x3);
+    x3 = fp6_mul_by_3b(t2);
+    Fp6 z3 = fp6_add(x3, t4);
+    x3 = fp6_sub(t1, z3);
+    z3 = fp6_add(t1, z3);
+    Fp6 y3 = fp6_mul(x3, z3);
+    t1 = fp6_double(t0);
+    t1 = fp6_add(t1, t0);
+    t4 = fp6_mul_by_3b(t4);
+    t1 = fp6_add(t1, t2);
+    t2 = fp6_sub(t0, t2);
+    t4 = fp6_add(t4, t2);
+    t0 = fp6_mul(t1, t4);
+    y3 = fp6_add(y3, t0);
+    t0 = fp6_mul(t5, t4);
+    x3 = fp6_mul(t3, x3);
+    x3 = fp6_sub(x3, t0);
+    t0 = fp6_mul(t3, t1);
+    z3 = fp6_mul(t5, z3);
+    z3 = fp6_add(z3, t0);
+    Proj o;
+    o.x = x3;
+    o.y = y3;
+    o.z = z3;
+    return o;
+}
+
+// src/curve/projective.rs:576-610 (incomplete; returns s when r is the identity)
+CH_DEV Proj proj_add_mixed_unchecked(const Proj& s, const Affine& r) {
+    Fp6 t0 = fp6_mul(r.y, s.z);
+    t0 = fp6_sub(t0, s.y);
+    Fp6 t1 = fp6_mul(r.x, s.z);
+    t1 = fp6_sub(t1, s.x);
+    Fp6 t2 = fp6_square(t0);
+    t2 = fp6_mul(t2, s.z);
+    Fp6 t3 = fp6_square(t1);
+    Fp6 t4 = fp6_mul(t1, t3);
+    t2 = fp6_sub(t2, t4);
+    Fp6 t5 = fp6_mul(t3, s.x);
+    Fp6 t6 = fp6_double(t5);
+    t2 = fp6_sub(t2, t6);
+    Fp6 x3 = fp6_mul(t1, t2);
+    Fp6 y3 = fp6_sub(t5, t2);
+    y3 = fp6_mul(y3, t0);
+    Fp6 t7 = fp6_mul(t4, s.y);
+    y3 = fp6_sub(y3, t7);
+    Fp6 z3 = fp6_mul(t4, s.z);
+    Proj o;
+    o.x = fp6_select(x3, s.x, r.inf);
+    o.y = fp6_select(y3, s.y, r.inf);
+    o.z = fp6_select(z3, s.z, r.inf);
+    return o;
+}
+
+// src/curve/jacobian.rs:1094-1128
+CH_DEV MJac mjac_double_unchecked(const MJac& s) {
+    Fp6 x_sq = fp6_square(s.x);
+    Fp6 y_sq = fp6_square(s.y);
+    Fp6 y_sq2 = fp6_square(y_sq);
+    Fp6 a = fp6_mul_small(y_sq, 4u);
+    a = fp6_mul(a, s.x);
+    Fp6 b = fp6_triple(x_sq);
+    b = fp6_add(b, s.z4);
+    Fp6 c = fp6_mul_small(y_sq2, 8u);
+    Fp6 x3 = fp6_square(b);
+    x3 = fp6_sub(x3, fp6_double(a));
+    Fp6 y3 = fp6_sub(a, x3);
+    y3 = fp6_mul(y3, b);
+    y3 = fp6_sub(y3, c);
+    Fp6 z3 = fp6_double(s.y);
+    z3 = fp6_mul(z3, s.z);
+    Fp6 z34 = fp6_double(c);
+    z34 = fp6_mul(z34, s.z4);
+    MJac o;
+    o.x = x3;
+    o.y = y3;
+    o.z = z3;
+    o.z4 = z34;
+    return o;
+}
+
+// src/curve/jacobian.rs:1146-1186
+CH_DEV MJac mjac_add_mixed_unchecked(const MJac& s, const Affine& r) {
+    Fp6 z1_sq = fp6_square(s.z);
+    Fp6 b = fp6_mul(r.x, z1_sq);
+    Fp6 d = fp6_mul(s.z, z1_sq);
+    d = fp6_mul(d, r.y);
+    Fp6 e = fp6_sub(b, s.x);
+    Fp6 f = fp6_sub(d, s.y);
+    Fp6 e_sq = fp6_square(e);
+    Fp6 e_sq_e = fp6_mul(e, e_sq);
+    Fp6 x_e_sq = fp6_mul(s.x, e_sq);
+    Fp6 x3 = fp6_square(f);
+    x3 = fp6_sub(x3, e_sq_e);
+    x3 = fp6_sub(x3, fp6_double(x_e_sq));
+    Fp6 y3 = fp6_sub(x_e_sq, x3);
+    y3 = fp6_mul(y3, f);
+    Fp6 t3 = fp6_mul(s.y, e_sq_e);
+    y3 = fp6_sub(y3, t3);
+    Fp6 z3 = fp6_mul(s.z, e);
+    Fp6 z34 = fp6_square(z3);
+    z34 = fp6_square(z34);
+    MJac o;
+    o.x = fp6_select(x3, s.x, r.inf);
+    o.y = fp6_select(y3, s.y, r.inf);
+    o.z = fp6_select(z3, s.z, r.inf);
+    o.z4 = fp6_select(z34, s.z4, r.inf);
+    return o;
+}
+
+// Single-point normalisations (one Fp6 inversion each).
+// src/curve/affine.rs:64-78
+CH_DEV Affine affine_from_proj(const Proj& p) {
+    bool some;
+    Fp6 zinv = fp6_invert(p.z, &some);
+    Affine a;
+    a.x = fp6_mul(p.x, zinv);
+    a.y = fp6_mul(p.y, zinv);
+    a.inf = false;
+    if (!some) a = affine_identity();
+    return a;
+}
+// src/curve/affine.rs:86-101
+CH_DEV Affine affine_from_jac(const Proj& p) {
+    Fp6 z3 = fp6_mul(fp6_square(p.z), p.z);
+    bool some;
+    Fp6 zinv3 = fp6_invert(z3, &some);
+    Affine a;
+    a.x = fp6_mul(fp6_mul(p.x, zinv3), p.z);
+    a.y = fp6_mul(p.y, zinv3);
+    a.inf = false;
+    if (!some) a = affine_identity();
+    return a;
+}
+
+}  // namespace cheetah

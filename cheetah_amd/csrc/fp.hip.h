@@ -1,0 +1,191 @@
+// Goldilocks field Fp (p = 2^64 - 2^32 + 1) device arithmetic for gfx950.
+//
+// Semantics follow the reference's src/fp.rs: an element is ANY u64 (not kept
+// canonical, src/fp.rs:57); results are congruent mod p to the reference's and
+// are canonicalised (`% p`, src/fp.rs:125-127) only when they leave the GPU.
+//
+// Measured on MI355X (tools/valu_peak.hip, profiles/valu_peak_r01.json):
+// v_mad_u64_u32 issues at the same rate as v_add_co_u32 / v_addc_co_u32
+// (one wave64 instruction per 4 cycles per SIMD), so the cost of this path is
+// the NUMBER of VALU instructions, not the number of multiplies.  The design
+// therefore (a) multiplies schoolbook on 32-bit limbs, (b) accumulates many
+// 32x32 products in 64-bit column accumulators with one carry add per product
+// and (c) reduces mod p once per accumulated sum (Acc3 below) instead of once
+// per product as the reference does (src/fp.rs:178-182, :623-646).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cheetah {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define CH_DEV __device__ __forceinline__
+
+constexpr u64 FP_P = 0xffffffff00000001ull;  // src/fp.rs:35
+constexpr u64 FP_EPS = 0xffffffffull;        // src/fp.rs:42  (2^64 mod p)
+
+CH_DEV u32 lo32(u64 x) { return (u32)x; }
+CH_DEV u32 hi32(u64 x) { return (u32)(x >> 32); }
+CH_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// a + b mod p; any u64 in, any u64 out.            (src/fp.rs:136-141)
+CH_DEV u64 fp_add(u64 a, u64 b) {
+    u64 s;
+    bool c = __builtin_uaddll_overflow(a, b, (unsigned long long*)&s);
+    u64 t;
+    bool c2 = __builtin_uaddll_overflow(s, c ? FP_EPS : 0ull, (unsigned long long*)&t);
+    return t + (c2 ? FP_EPS : 0ull);
+}
+
+// a - b mod p.                                     (src/fp.rs:163-168)
+CH_DEV u64 fp_sub(u64 a, u64 b) {
+    u64 s;
+    bool c = __builtin_usubll_overflow(a, b, (unsigned long long*)&s);
+    u64 t;
+    bool c2 = __builtin_usubll_overflow(s, c ? FP_EPS : 0ull, (unsigned long long*)&t);
+    return t - (c2 ? FP_EPS : 0ull);
+}
+
+CH_DEV u64 fp_neg(u64 a) { return fp_sub(0ull, a); }     // src/fp.rs:172-174
+CH_DEV u64 fp_double(u64 a) { return fp_add(a, a); }     // src/fp.rs:145-150
+
+// Canonical representative in [0, p).               (src/fp.rs:125-127)
+CH_DEV u64 fp_canonical(u64 a) { return a >= FP_P ? a - FP_P : a; }
+CH_DEV bool fp_is_zero(u64 a) { return a == 0ull || a == FP_P; }
+
+// ---------------------------------------------------------------------------
+// Column accumulators.  A sum of 64x64 products is kept as three 64-bit columns
+// (weights 2^0, 2^32, 2^64), each with a 32-bit count of the carries out of it:
+//   value = c0 + 2^32 c1 + 2^64 c2 + 2^64 t0 + 2^96 t1 + 2^128 t2
+// One product costs 4 v_mad_u64_u32 + 4 v_addc_co_u32.  The carry of each mad
+// is delivered in an SGPR pair, and gfx950 needs two wait states between a VALU
+// write of an SGPR and a VALU read of it (the compiler pads its own code with
+// s_nop for this; inside an asm block it is on us), so the eight instructions
+// of a product are ordered such that two others always separate a mad from the
+// addc that consumes its carry -- no s_nop is spent.
+struct Acc3 {
+    u64 c0, c1, c2;
+    u32 t0, t1, t2;
+
+    // acc = a * b
+    CH_DEV void init(u64 a, u64 b) {
+        u64 s0, s1, s2;
+        asm("v_mad_u64_u32 %[c1], %[s1], %[al], %[bh], 0\n\t"
+            "v_mad_u64_u32 %[c0], %[s0], %[al], %[bl], 0\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[ah], %[bh], 0\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[ah], %[bl], %[c1]\n\t"
+            "v_mov_b32 %[t0], 0\n\t"
+            "v_mov_b32 %[t2], 0\n\t"
+            "v_addc_co_u32 %[t1], %[s1], 0, 0, %[s1]"
+            : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+              [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [al] "v"(lo32(a)), [ah] "v"(hi32(a)), [bl] "v"(lo32(b)), [bh] "v"(hi32(b)));
+    }
+    // acc += a * b
+    CH_DEV void mac(u64 a, u64 b) {
+        u64 s0, s1, s2;
+        asm("v_mad_u64_u32 %[c1], %[s1], %[al], %[bh], %[c1]\n\t"
+            "v_mad_u64_u32 %[c0], %[s0], %[al], %[bl], %[c0]\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[ah], %[bh], %[c2]\n\t"
+            "v_addc_co_u32 %[t1], %[s1], 0, %[t1], %[s1]\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[ah], %[bl], %[c1]\n\t"
+            "v_addc_co_u32 %[t0], %[s0], 0, %[t0], %[s0]\n\t"
+            "v_addc_co_u32 %[t2], %[s2], 0, %[t2], %[s2]\n\t"
+            "v_addc_co_u32 %[t1], %[s1], 0, %[t1], %[s1]"
+            : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2),
+              [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [al] "v"(lo32(a)), [ah] "v"(hi32(a)), [bl] "v"(lo32(b)), [bh] "v"(hi32(b)));
+    }
+    // acc = a * k0 + b * k1 for 32-bit k0, k1 (no column can overflow: t's are zero)
+    CH_DEV void init_small2(u64 a, u32 k0, u64 b, u32 k1) {
+        // each partial product < 2^64 - 2^33; columns 0 and 1 get two each
+        u64 p0 = (u64)lo32(a) * k0, q0 = (u64)lo32(b) * k1;
+        u64 p1 = (u64)hi32(a) * k0, q1 = (u64)hi32(b) * k1;
+        bool cy0 = __builtin_uaddll_overflow(p0, q0, (unsigned long long*)&c0);
+        bool cy1 = __builtin_uaddll_overflow(p1, q1, (unsigned long long*)&c1);
+        t0 = cy0 ? 1u : 0u;
+        t1 = cy1 ? 1u : 0u;
+        c2 = 0;
+        t2 = 0;
+    }
+
+    // The accumulated integer modulo p, as some u64.
+    // With 2^64 = eps, 2^96 = -1, 2^128 = -2^32 (mod p) -- the fold of
+    // src/fp.rs:623-646 applied once to the whole sum:
+    //   w = 5-word integer (w4 small);  V = (w1:w0) + eps*w2 - (w3 + 2^32 w4)
+    CH_DEV u64 reduce() const {
+        u32 w0 = lo32(c0);
+        // w1..w4 by one carry chain; the t's ride along where their weight allows
+        u64 s1 = (u64)hi32(c0) + lo32(c1);
+        u32 w1 = lo32(s1);
+        u64 s2 = (u64)hi32(c1) + lo32(c2) + hi32(s1);
+        u64 s2b = (u64)lo32(s2) + t0;
+        u32 w2 = lo32(s2b);
+        u64 s3 = (u64)hi32(c2) + t1 + hi32(s2) + hi32(s2b);
+        u32 w3 = lo32(s3);
+        u32 w4 = t2 + hi32(s3);
+        // R = (w1:w0) + eps * w2, carry worth 2^64 = eps (cannot overflow twice)
+        u64 a = mk64(w0, w1);
+        u64 e = ((u64)w2 << 32) - w2;
+        u64 r;
+        bool c = __builtin_uaddll_overflow(a, e, (unsigned long long*)&r);
+        r += c ? FP_EPS : 0ull;
+        // R -= w3 + 2^32 w4, borrow worth -2^64 = -eps (cannot borrow twice)
+        u64 d = mk64(w3, w4);
+        u64 q;
+        bool b = __builtin_usubll_overflow(r, d, (unsigned long long*)&q);
+        q -= b ? FP_EPS : 0ull;
+        return q;
+    }
+};
+
+// a * b mod p.                                      (src/fp.rs:178-182)
+CH_DEV u64 fp_mul(u64 a, u64 b) {
+    Acc3 acc;
+    acc.init(a, b);
+    return acc.reduce();
+}
+CH_DEV u64 fp_square(u64 a) { return fp_mul(a, a); }  // src/fp.rs:194-196
+
+// a * k mod p for a small constant k (k * 2^64 must fit the folds: k < 2^31).  (src/fp.rs:186-190)
+CH_DEV u64 fp_mul_small(u64 a, u32 k) {
+    u64 l = (u64)lo32(a) * k;             // < 2^63
+    u64 h = (u64)hi32(a) * k + hi32(l);   // < 2^63; value = lo32(l) + 2^32 h
+    // 2^32 * h = 2^32 lo32(h) + 2^64 hi32(h) = 2^32 lo32(h) + eps * hi32(h)
+    u64 base = mk64(lo32(l), lo32(h));
+    u64 e = (u64)hi32(h) * FP_EPS;        // hi32(h) < 2^31
+    u64 r;
+    bool c = __builtin_uaddll_overflow(base, e, (unsigned long long*)&r);
+    return r + (c ? FP_EPS : 0ull);
+}
+
+CH_DEV u64 fp_triple(u64 a) { return fp_mul_small(a, 3u); }  // src/fp.rs:154-159
+
+CH_DEV u64 fp_sqn(u64 a, int n) {
+    for (int i = 0; i < n; i++) a = fp_square(a);
+    return a;
+}
+
+// a^(p-2) by the reference's addition chain (src/fp.rs:335-359); 0 -> 0.
+CH_DEV u64 fp_invert(u64 a) {
+    u64 t2 = fp_square(a);
+    u64 t3 = fp_mul(t2, a);
+    u64 t0 = fp_sqn(t3, 2);
+    t2 = fp_mul(t2, t0);
+    t3 = fp_mul(t3, t0);
+    t0 = fp_sqn(t3, 4);
+    t2 = fp_mul(t2, t0);
+    t3 = fp_mul(t3, t0);
+    t0 = fp_sqn(t3, 8);
+    t2 = fp_mul(t2, t0);
+    t0 = fp_mul(t0, t3);
+    t0 = fp_sqn(t0, 16);
+    t2 = fp_mul(t2, t0);
+    t0 = fp_sqn(t2, 32);
+    t0 = fp_mul(t0, t2);
+    return fp_mul(t0, a);
+}
+
+}  // namespace cheetah

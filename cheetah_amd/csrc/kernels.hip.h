@@ -1,0 +1,586 @@
+// HIP kernels of the batched Cheetah engine (gfx950).  One curve point (or one
+// Fp6 element) per lane; 256-thread workgroups = 4 waves = one wave per SIMD.
+#pragma once
+#include "curve.hip.h"
+
+namespace cheetah {
+
+typedef uint8_t u8;
+typedef int8_t i8;
+
+constexpr int BLOCK = 256;
+
+// ---------------------------------------------------------------------------
+// Precomputed tables, built on the device at context creation.
+struct DeviceTables {
+    u64 basepoint[32 * 8 * 12];  // BASEPOINT_TABLE: table-major, entry-major, x|y   src/lookup.rs:136
+    u64 shift[12];               // S                                                src/constants.rs:43-61
+    u64 minus_shift_4[12];       // MINUS_SHIFT_POINT_ARRAY[4]   = -2^4 S            src/constants.rs:76-90
+    u64 minus_shift_256[12];     // MINUS_SHIFT_POINT_ARRAY[256] = -2^256 S
+};
+
+// ---- AoS <-> register helpers --------------------------------------------
+CH_DEV Fp6 load_fp6(const u64* p) {
+    Fp6 r;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.c[i] = p[i];
+    return r;
+}
+CH_DEV void store_fp6_canonical(u64* p, const Fp6& a) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) p[i] = fp_canonical(a.c[i]);
+}
+CH_DEV Affine load_affine(const u64* p) {
+    Affine a;
+    a.x = load_fp6(p);
+    a.y = load_fp6(p + 6);
+    a.inf = false;
+    return a;
+}
+CH_DEV Proj load_proj(const u64* p) {
+    Proj r;
+    r.x = load_fp6(p);
+    r.y = load_fp6(p + 6);
+    r.z = load_fp6(p + 12);
+    return r;
+}
+CH_DEV void store_affine(u64* xy, u8* inf, size_t i, const Affine& a) {
+    store_fp6_canonical(xy + 12 * i, a.x);
+    store_fp6_canonical(xy + 12 * i + 6, a.y);
+    if (inf) inf[i] = a.inf ? 1 : 0;
+}
+CH_DEV void store_proj(u64* out, u8* inf, size_t i, const Proj& p) {
+    store_fp6_canonical(out + 18 * i, p.x);
+    store_fp6_canonical(out + 18 * i + 6, p.y);
+    store_fp6_canonical(out + 18 * i + 12, p.z);
+    if (inf) inf[i] = fp6_is_zero(p.z) ? 1 : 0;
+}
+// out_form 0: normalise (one Fp6 inversion per lane), 1: the projective representative as is
+template <int OUT_FORM>
+CH_DEV void emit_point(u64* out, u8* inf, size_t i, const Proj& p) {
+    if (OUT_FORM == 0)
+        store_affine(out, inf, i, affine_from_proj(p));
+    else
+        store_proj(out, inf, i, p);
+}
+
+// ---------------------------------------------------------------------------
+// Table construction (context creation).  Thread t < 32 builds LookupTable<8> of
+// 256^t G (src/lookup.rs:164-173, :25-37); thread 32 builds -2^4 S and -2^256 S
+// (src/constants.rs:80-90).  Entries are affine, hence independent of how they
+// were computed.
+__global__ void __launch_bounds__(64) k_build_tables(DeviceTables* tab, const u64* gen_xy, const u64* shift_xy) {
+    const int t = threadIdx.x;
+    if (t < 32) {
+        Proj base = proj_from_affine(load_affine(gen_xy));
+        for (int i = 0; i < 8 * t; i++) base = proj_double(base);
+        Proj cur = base;
+        for (int j = 0; j < 8; j++) {
+            if (j > 0) cur = proj_add(base, cur);
+            Affine a = affine_from_proj(cur);
+            store_affine(tab->basepoint, nullptr, (size_t)(8 * t + j), a);
+        }
+    } else if (t == 32) {
+        Affine s = load_affine(shift_xy);
+        store_affine(tab->shift, nullptr, 0, s);
+        Proj cur = proj_from_affine(s);
+        cur.y = fp6_neg(cur.y);
+        for (int i = 1; i <= 256; i++) {
+            cur = proj_double(cur);
+            if (i == 4) store_affine(tab->minus_shift_4, nullptr, 0, affine_from_proj(cur));
+        }
+        store_affine(tab->minus_shift_256, nullptr, 0, affine_from_proj(cur));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise Fp6 kernels (config 1): HBM-bound, 144 B per multiplication.
+// AoS elements are 48 B, so a lane's own element is not a coalesced access:
+// each workgroup moves its 256-element tile (12 KiB per operand) between HBM
+// and LDS with fully coalesced 8-byte accesses and lanes pick their element
+// out of LDS.
+enum { EW_MUL = 0, EW_SQUARE = 1, EW_INVERT = 2 };
+
+template <int OP>
+__global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict__ a, const u64* __restrict__ b,
+                                                           u64* __restrict__ out, u8* __restrict__ is_some, size_t n) {
+    __shared__ u64 sa[BLOCK * 6];
+    __shared__ u64 sb[OP == EW_MUL ? BLOCK * 6 : 1];
+    const int t = threadIdx.x;
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t e0 = tile * BLOCK;
+        const size_t cnt = (n - e0 < (size_t)BLOCK) ? n - e0 : (size_t)BLOCK;
+        const size_t words = cnt * 6;
+        const u64* ga = a + e0 * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            size_t w = (size_t)t + (size_t)k * BLOCK;
+            if (w < words) sa[w] = ga[w];
+        }
+        if (OP == EW_MUL) {
+            const u64* gb = b + e0 * 6;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                size_t w = (size_t)t + (size_t)k * BLOCK;
+                if (w < words) sb[w] = gb[w];
+            }
+        }
+        __syncthreads();
+        Fp6 r = fp6_zero();
+        bool some = true;
+        if ((size_t)t < cnt) {
+            Fp6 x = load_fp6(sa + 6 * t);
+            if (OP == EW_MUL)
+                r = fp6_mul(x, load_fp6(sb + 6 * t));
+            else if (OP == EW_SQUARE)
+                r = fp6_square(x);
+            else
+                r = fp6_invert(x, &some);
+        }
+        __syncthreads();
+        if ((size_t)t < cnt) {
+            store_fp6_canonical(sa + 6 * t, r);
+            if (OP == EW_INVERT && is_some) is_some[e0 + t] = some ? 1 : 0;
+        }
+        __syncthreads();
+        u64* go = out + e0 * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            size_t w = (size_t)t + (size_t)k * BLOCK;
+            if (w < words) go[w] = sa[w];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// batch_normalize (config 4).  The reference runs ONE sequential Montgomery
+// chain over the whole slice (src/curve/projective.rs:897-930,
+// src/curve/jacobian.rs:886-920).  Here every lane runs the same trick over its
+// own CHUNK consecutive points: prefix products of the non-zero z's, one Fp6
+// inversion per lane, then the backward pass.  Identities (z = 0) are skipped in
+// the chain and come out as (0, 1, inf = 1) exactly as in the reference.
+// Exact field arithmetic makes the re-association invisible in the results.
+template <int JAC, int CHUNK>
+__global__ void __launch_bounds__(BLOCK) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
+                                                           u8* __restrict__ inf, size_t n) {
+    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    for (size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * BLOCK) {
+        const size_t e0 = c * CHUNK;
+        Fp6 prefix[CHUNK];  // prefix[j] = product of non-zero z's before point j
+        Fp6 acc = fp6_one();
+#pragma unroll
+        for (int j = 0; j < CHUNK; j++) {
+            prefix[j] = acc;
+            if (e0 + j < n) {
+                Fp6 z = load_fp6(xyz + 18 * (e0 + j) + 12);
+                Fp6 m = fp6_mul(acc, z);
+                acc = fp6_select(m, acc, fp6_is_zero(z));
+            }
+        }
+        bool some;
+        acc = fp6_invert(acc, &some);
+#pragma unroll
+        for (int j = CHUNK - 1; j >= 0; j--) {
+            if (e0 + j < n) {
+                const u64* p = xyz + 18 * (e0 + j);
+                Fp6 z = load_fp6(p + 12);
+                const bool skip = fp6_is_zero(z);
+                Fp6 zi = fp6_mul(prefix[j], acc);  // 1 / z_j
+                Fp6 m = fp6_mul(acc, z);
+                acc = fp6_select(m, acc, skip);
+                Affine o;
+                if (JAC) {
+                    Fp6 zi2 = fp6_square(zi);
+                    o.x = fp6_mul(load_fp6(p), zi2);
+                    o.y = fp6_mul(fp6_mul(load_fp6(p + 6), zi2), zi);
+                } else {
+                    o.x = fp6_mul(load_fp6(p), zi);
+                    o.y = fp6_mul(load_fp6(p + 6), zi);
+                }
+                o.inf = false;
+                if (skip) o = affine_identity();
+                store_affine(xy, inf, e0 + j, o);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scalar recoding (src/scalar.rs:531-548): 32 bytes -> 64 signed radix-16 digits
+// in [-8, 8) (digit 63 is left un-recentred, up to 16).  Digits go to LDS,
+// digit-major, one byte per lane.
+CH_DEV void recode_radix16(const u64 k[4], i8* digits /* [64][BLOCK] */, int t) {
+    int carry = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        u64 v = k[w];
+        for (int j = 0; j < 16; j++) {
+            const int i = 16 * w + j;
+            int d = (int)(v & 0xf) + carry;
+            v >>= 4;
+            if (i < 63) {
+                carry = (d + 8) >> 4;
+                d -= carry << 4;
+            }
+            digits[i * BLOCK + t] = (i8)d;
+        }
+    }
+}
+
+// Width-w NAF (src/scalar.rs:585-643), one digit per bit position, to LDS.
+CH_DEV void recode_wnaf(const u64 k[4], int w, i8* naf /* [256][BLOCK] */, int t) {
+    for (int i = 0; i < 256; i++) naf[i * BLOCK + t] = 0;
+    const u32 width = 1u << w, mask = width - 1;
+    u32 carry = 0;
+    int pos = 0;
+    while (pos < 256) {
+        const int idx = pos >> 6, bit = pos & 63;
+        // x_u64[idx] with the reference's fifth, zero word
+        u64 lo = idx == 0 ? k[0] : idx == 1 ? k[1] : idx == 2 ? k[2] : k[3];
+        u64 hi = idx == 0 ? k[1] : idx == 1 ? k[2] : idx == 2 ? k[3] : 0ull;
+        u64 buf = (bit < 64 - w) ? (lo >> bit) : ((lo >> bit) | (hi << (64 - bit)));
+        const u32 window = carry + ((u32)buf & mask);
+        if ((window & 1) == 0) {
+            pos += 1;
+            continue;
+        }
+        if (window < width / 2) {
+            carry = 0;
+            naf[pos * BLOCK + t] = (i8)window;
+        } else {
+            carry = 1;
+            naf[pos * BLOCK + t] = (i8)((int)window - (int)width);
+        }
+        pos += w;
+    }
+}
+
+CH_DEV void load_scalar(const u8* scalars, size_t i, u64 k[4]) {
+    const u64* p = reinterpret_cast<const u64*>(scalars + 32 * i);
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j] = p[j];
+}
+
+// ---------------------------------------------------------------------------
+// Fixed base, constant time (config 2): BasePointTable::multiply,
+// src/lookup.rs:189-206.  The 24 KiB table sits in LDS; a lookup reads all 8
+// entries of the digit's sub-table (every lane the same addresses: an LDS
+// broadcast) and keeps the one it wants by selects -- the reference's
+// constant-time scan (src/lookup.rs:81-102).
+CH_DEV Affine lds_lookup8(const u64* sub /* 8 x 12 limbs in LDS */, int d) {
+    const int neg = d < 0;
+    const int dabs = neg ? -d : d;
+    Affine t = affine_identity();
+#pragma unroll
+    for (int j = 1; j <= 8; j++) {
+        const bool hit = (dabs == j);
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            u64 vx = sub[(j - 1) * 12 + l], vy = sub[(j - 1) * 12 + 6 + l];
+            t.x.c[l] = hit ? vx : t.x.c[l];
+            t.y.c[l] = hit ? vy : t.y.c[l];
+        }
+        t.inf = hit ? false : t.inf;
+    }
+    return affine_cond_neg(t, neg);
+}
+
+template <int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK) k_mul_by_generator(const DeviceTables* __restrict__ tab,
+                                                            const u8* __restrict__ scalars, u64* __restrict__ out,
+                                                            u8* __restrict__ inf, size_t n) {
+    __shared__ u64 s_tab[32 * 8 * 12];
+    __shared__ i8 s_digits[64 * BLOCK];
+    const int t = threadIdx.x;
+    for (int w = t; w < 32 * 8 * 12; w += BLOCK) s_tab[w] = tab->basepoint[w];
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift4 = load_affine(tab->minus_shift_4);
+    const size_t nround = (n + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i = round * BLOCK + t;
+        const bool active = i < n;
+        u64 k[4];
+        load_scalar(scalars, active ? i : n - 1, k);
+        __syncthreads();
+        recode_radix16(k, s_digits, t);
+        __syncthreads();
+        const bool in_range = (k[3] >> 60) <= 7;  // LookupTable<8> covers the top digit only then (Q3)
+        Proj acc = proj_from_affine(shift);
+        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
+        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        acc = proj_add_mixed_unchecked(acc, mshift4);
+        if (active) {
+            emit_point<OUT_FORM>(out, inf, i, acc);
+            if (!in_range && inf) inf[i] = 0xFF;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Variable base (configs 3 and 5).  Each lane owns a window table in global
+// scratch, laid out [entry][limb][lane] per workgroup so that every access is a
+// coalesced 512 B per wave.
+struct LaneScratch {
+    // per workgroup: tab[16][12][BLOCK], z[16][6][BLOCK], prefix[16][6][BLOCK]
+    static constexpr size_t WORDS_PER_BLOCK = (size_t)16 * 24 * BLOCK;
+};
+
+CH_DEV void sc_store(u64* base, int entry, int limb0, const Fp6& v, int t, int rows) {
+#pragma unroll
+    for (int l = 0; l < 6; l++) base[((size_t)entry * rows + limb0 + l) * BLOCK + t] = v.c[l];
+}
+CH_DEV Fp6 sc_load(const u64* base, int entry, int limb0, int t, int rows) {
+    Fp6 v;
+#pragma unroll
+    for (int l = 0; l < 6; l++) v.c[l] = base[((size_t)entry * rows + limb0 + l) * BLOCK + t];
+    return v;
+}
+
+// Builds the affine multiples m_0 P, m_1 P, ... in the lane's scratch table:
+//   STEP2 = false: P, 2P, ..., NP         (LookupTable<N>,    src/lookup.rs:25-37)
+//   STEP2 = true : P, 3P, ..., (2N-1)P    (NafLookupTable<N>, src/naf_lookup.rs:35-48)
+// with the reference's complete additions and one Montgomery inversion per
+// lane (its batch_normalize, src/curve/projective.rs:897-930).  Returns a bit
+// mask of the entries that are the identity.
+template <bool STEP2>
+CH_DEV u32 build_table(const Proj& p, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
+    Proj step = STEP2 ? proj_double(p) : p;
+    Proj cur = p;
+    Fp6 acc = fp6_one();
+    u32 ident = 0;
+    for (int j = 0; j < n_entries; j++) {
+        if (j > 0) cur = proj_add(step, cur);
+        sc_store(s_tab, j, 0, cur.x, t, 12);
+        sc_store(s_tab, j, 6, cur.y, t, 12);
+        sc_store(s_z, j, 0, cur.z, t, 6);
+        sc_store(s_prefix, j, 0, acc, t, 6);
+        const bool skip = fp6_is_zero(cur.z);
+        ident |= skip ? (1u << j) : 0u;
+        Fp6 m = fp6_mul(acc, cur.z);
+        acc = fp6_select(m, acc, skip);
+    }
+    bool some;
+    acc = fp6_invert(acc, &some);
+    for (int j = n_entries - 1; j >= 0; j--) {
+        Fp6 z = sc_load(s_z, j, 0, t, 6);
+        Fp6 zi = fp6_mul(sc_load(s_prefix, j, 0, t, 6), acc);
+        const bool skip = (ident >> j) & 1;
+        Fp6 m = fp6_mul(acc, z);
+        acc = fp6_select(m, acc, skip);
+        Fp6 x = fp6_mul(sc_load(s_tab, j, 0, t, 12), zi);
+        Fp6 y = fp6_mul(sc_load(s_tab, j, 6, t, 12), zi);
+        sc_store(s_tab, j, 0, fp6_select(x, fp6_zero(), skip), t, 12);
+        sc_store(s_tab, j, 6, fp6_select(y, fp6_one(), skip), t, 12);
+    }
+    return ident;
+}
+
+// Constant-time lookup (src/lookup.rs:81-102): read every entry, keep entry |d|.
+CH_DEV Affine scan_lookup(const u64* s_tab, int n_entries, u32 ident, int d, int t) {
+    const int neg = d < 0;
+    const int dabs = neg ? -d : d;
+    Affine r = affine_identity();
+    for (int j = 1; j <= n_entries; j++) {
+        const bool hit = (dabs == j);
+        Fp6 x = sc_load(s_tab, j - 1, 0, t, 12);
+        Fp6 y = sc_load(s_tab, j - 1, 6, t, 12);
+        r.x = fp6_select(r.x, x, hit);
+        r.y = fp6_select(r.y, y, hit);
+        r.inf = hit ? (bool)((ident >> (j - 1)) & 1) : r.inf;
+    }
+    return affine_cond_neg(r, neg);
+}
+
+template <int IN_FORM>
+CH_DEV Proj load_input_point(const u64* pts, size_t i) {
+    if (IN_FORM == 0) {
+        Affine a = load_affine(pts + 12 * i);
+        // (0, 1) is the affine encoding of the identity (src/curve/affine.rs:224-230)
+        a.inf = fp6_is_zero(a.x) && fp_canonical(a.y.c[0]) == 1 && fp_is_zero(a.y.c[1]) && fp_is_zero(a.y.c[2]) &&
+                fp_is_zero(a.y.c[3]) && fp_is_zero(a.y.c[4]) && fp_is_zero(a.y.c[5]);
+        return proj_from_affine(a);
+    }
+    return load_proj(pts + 18 * i);
+}
+
+// ProjectivePoint::multiply, src/curve/projective.rs:614-625.
+template <int IN_FORM, int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
+                                                       const u8* __restrict__ scalars, u64* __restrict__ out,
+                                                       u8* __restrict__ inf, size_t n, u64* __restrict__ scratch) {
+    __shared__ i8 s_digits[64 * BLOCK];
+    const int t = threadIdx.x;
+    u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
+    u64* s_z = s_tab + (size_t)16 * 12 * BLOCK;
+    u64* s_prefix = s_z + (size_t)16 * 6 * BLOCK;
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t nround = (n + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i = round * BLOCK + t;
+        const bool active = i < n;
+        const size_t ii = active ? i : n - 1;
+        u64 k[4];
+        load_scalar(scalars, ii, k);
+        __syncthreads();
+        recode_radix16(k, s_digits, t);
+        __syncthreads();
+        // canonical scalars (< 2^255) only ever select entries 1..8; a wave builds
+        // all 16 entries of LookupTable<16> only if one of its lanes needs them
+        const bool wide = (k[3] >> 60) > 7;
+        const int n_entries = __any(wide) ? 16 : 8;
+        const Proj p = load_input_point<IN_FORM>(pts, ii);
+        const u32 ident = build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
+        Proj acc = proj_from_affine(shift);
+        for (int j = 63; j >= 0; j--) {
+            for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
+            acc = proj_add_mixed_unchecked(acc, scan_lookup(s_tab, n_entries, ident, s_digits[j * BLOCK + t], t));
+        }
+        acc = proj_add_mixed_unchecked(acc, mshift);
+        if (active) emit_point<OUT_FORM>(out, inf, i, acc);
+    }
+}
+
+// ProjectivePoint::multiply_vartime, src/curve/projective.rs:633-662, with its
+// quirk Q1: the "skip unset digits" loop never moves i off 255, so there are
+// always 256 doublings and the correction is MINUS_SHIFT_POINT_ARRAY[256].
+// Lanes add only where their own NAF digit is non-zero (divergent by nature).
+template <int IN_FORM, int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK) k_multiply_vartime(const DeviceTables* __restrict__ tab,
+                                                            const u64* __restrict__ pts, const u8* __restrict__ scalars,
+                                                            u64* __restrict__ out, u8* __restrict__ inf, size_t n,
+                                                            u64* __restrict__ scratch) {
+    __shared__ i8 s_naf[256 * BLOCK];
+    const int t = threadIdx.x;
+    u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
+    u64* s_z = s_tab + (size_t)16 * 12 * BLOCK;
+    u64* s_prefix = s_z + (size_t)16 * 6 * BLOCK;
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t nround = (n + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i = round * BLOCK + t;
+        const bool active = i < n;
+        const size_t ii = active ? i : n - 1;
+        u64 k[4];
+        load_scalar(scalars, ii, k);
+        __syncthreads();
+        recode_wnaf(k, 5, s_naf, t);
+        __syncthreads();
+        const Proj p = load_input_point<IN_FORM>(pts, ii);
+        const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
+        Proj acc = proj_from_affine(shift);
+        for (int j = 255; j >= 0; j--) {
+            acc = proj_double_unchecked(acc);
+            const int d = s_naf[j * BLOCK + t];
+            if (d != 0) {
+                const int e = (d < 0 ? -d : d) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
+                Affine q;
+                q.x = sc_load(s_tab, e, 0, t, 12);
+                q.y = sc_load(s_tab, e, 6, t, 12);
+                q.inf = (ident >> e) & 1;
+                acc = proj_add_mixed_unchecked(acc, affine_cond_neg(q, d < 0));
+            }
+        }
+        acc = proj_add_mixed_unchecked(acc, mshift);
+        if (active) emit_point<OUT_FORM>(out, inf, i, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic inputs: the generator of cheetah_amd/synth.py on the device.
+CH_DEV u64 splitmix64(u64 seed, u64 idx) {
+    u64 z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(BLOCK) k_synth_fp6(u64 seed, u64 start, u64* out, size_t n_words) {
+    for (size_t w = (size_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (size_t)gridDim.x * BLOCK)
+        out[w] = fp_canonical(splitmix64(seed, 6 * start + w));
+}
+__global__ void __launch_bounds__(BLOCK) k_synth_scalars(u64 seed, u64 start, u64* out, size_t n) {
+    // q = 0x7af2599b3b3f22d0563fbf0f990a37b5327aa72330157722d443623eaed4accf  (src/scalar.rs:41-46)
+    const u64 q[4] = {0xd443623eaed4accfull, 0x327aa72330157722ull, 0x563fbf0f990a37b5ull, 0x7af2599b3b3f22d0ull};
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        u64 v[4];
+        for (int j = 0; j < 4; j++) v[j] = splitmix64(seed, 4 * (start + i) + j);
+        for (int rep = 0; rep < 3; rep++) {  // 2^256 / q < 3
+            bool ge = true;  // v >= q ?
+            for (int j = 3; j >= 0; j--) {
+                if (v[j] != q[j]) {
+                    ge = v[j] > q[j];
+                    break;
+                }
+            }
+            if (ge) {
+                u64 borrow = 0;
+                for (int j = 0; j < 4; j++) {
+                    u64 d = v[j] - q[j] - borrow;
+                    borrow = (v[j] < q[j] + borrow) || (q[j] + borrow < borrow) ? 1 : 0;
+                    v[j] = d;
+                }
+            }
+        }
+        for (int j = 0; j < 4; j++) out[4 * i + j] = v[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Unit-level parity hook: one device function applied to n operand tuples.
+__global__ void __launch_bounds__(BLOCK) k_debug_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        switch (op) {
+            case 0: out[i] = fp_add(a[i], b[i]); break;
+            case 1: out[i] = fp_sub(a[i], b[i]); break;
+            case 2: out[i] = fp_mul(a[i], b[i]); break;
+            case 3: out[i] = fp_mul_small(a[i], 7u); break;
+            case 4: out[i] = fp_invert(a[i]); break;
+            case 16: { Fp6 r = fp6_add(load_fp6(a + 6 * i), load_fp6(b + 6 * i)); for (int l = 0; l < 6; l++) out[6 * i + l] = r.c[l]; break; }
+            case 17: { Fp6 r = fp6_sub(load_fp6(a + 6 * i), load_fp6(b + 6 * i)); for (int l = 0; l < 6; l++) out[6 * i + l] = r.c[l]; break; }
+            case 18: { Fp6 r = fp6_mul_by_3b(load_fp6(a + 6 * i)); for (int l = 0; l < 6; l++) out[6 * i + l] = r.c[l]; break; }
+            case 19: { Fp6 r = fp6_frobenius(load_fp6(a + 6 * i)); for (int l = 0; l < 6; l++) out[6 * i + l] = r.c[l]; break; }
+            case 32: store_proj(out, nullptr, i, proj_double_unchecked(load_proj(a + 18 * i))); break;
+            case 33: store_proj(out, nullptr, i, proj_add(load_proj(a + 18 * i), load_proj(b + 18 * i))); break;
+            case 34: store_proj(out, nullptr, i, proj_add_mixed_unchecked(load_proj(a + 18 * i), load_affine(b + 12 * i))); break;
+            case 35: {
+                MJac p; p.x = load_fp6(a + 24 * i); p.y = load_fp6(a + 24 * i + 6); p.z = load_fp6(a + 24 * i + 12); p.z4 = load_fp6(a + 24 * i + 18);
+                MJac r = mjac_double_unchecked(p);
+                store_fp6_canonical(out + 24 * i, r.x); store_fp6_canonical(out + 24 * i + 6, r.y);
+                store_fp6_canonical(out + 24 * i + 12, r.z); store_fp6_canonical(out + 24 * i + 18, r.z4);
+                break;
+            }
+            case 36: {
+                MJac p; p.x = load_fp6(a + 24 * i); p.y = load_fp6(a + 24 * i + 6); p.z = load_fp6(a + 24 * i + 12); p.z4 = load_fp6(a + 24 * i + 18);
+                MJac r = mjac_add_mixed_unchecked(p, load_affine(b + 12 * i));
+                store_fp6_canonical(out + 24 * i, r.x); store_fp6_canonical(out + 24 * i + 6, r.y);
+                store_fp6_canonical(out + 24 * i + 12, r.z); store_fp6_canonical(out + 24 * i + 18, r.z4);
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+// v_mad_u64_u32 issue-rate calibration (the roofline denominator): 8 independent
+// chains per lane, 8 waves per SIMD.
+__global__ void __launch_bounds__(BLOCK) k_mad_peak(u64* out, u32 seed, int iters) {
+    u64 acc[8];
+    u32 b = threadIdx.x * 2654435761u + seed, c = b ^ 0x9e3779b9u;
+    for (int i = 0; i < 8; i++) acc[i] = ((u64)b << 32) + i;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(b), "v"(c) : "vcc");
+        }
+    }
+    u64 r = 0;
+    for (int i = 0; i < 8; i++) r ^= acc[i];
+    if (r == 0x12345ull) out[0] = r;
+}
+
+}  // namespace cheetah

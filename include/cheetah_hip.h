@@ -1,0 +1,151 @@
+/*
+ * cheetah_hip.h -- C ABI of the MI355X (gfx950) batched Cheetah curve engine.
+ *
+ * The reference (toposware/cheetah 0.1.0) is a leaf Rust crate with no FFI or
+ * plugin surface (src/lib.rs:44 forbids unsafe); its API is one operation per
+ * call on its own types.  This header is the batch boundary a thin Rust `-sys`
+ * crate binds (INTEGRATION.md shows the binding): each entry point is the batch
+ * form of the reference function cited beside it and returns, element by
+ * element and in canonical limbs, what that function returns.
+ *
+ * Conventions
+ *  - Fp6      : 6 x uint64_t, c0..c5, exactly Fp6::output_internal()        (src/fp6.rs:1126-1135)
+ *  - affine   : 12 x uint64_t = x | y, plus one uint8_t infinity flag;
+ *               the identity is x = 0, y = 1, infinity = 1                   (src/curve/affine.rs:224-230)
+ *  - projective / jacobian : 18 x uint64_t = x | y | z                       (src/curve/projective.rs:213-225)
+ *  - scalar   : 32 canonical little-endian bytes, Scalar::to_bytes()         (src/scalar.rs:477-489)
+ *  - arrays are AoS, element i at index i; inputs may hold non-canonical
+ *    limbs (any u64, as Fp::from_raw_unchecked, src/fp.rs:363-365); outputs are
+ *    always canonical (each limb < p).
+ *  - every call returns 0 on success or a negative cheetah_status; nothing
+ *    aborts or throws across the boundary; cheetah_last_error() has the text.
+ *  - a context belongs to ONE device and one host thread at a time; calls are
+ *    issued on the context's stream.  `_dev` entry points take DEVICE pointers
+ *    (8-byte aligned) and are asynchronous on that stream; the others take HOST
+ *    pointers, copy, run the same kernels and return after the results are back.
+ *  - the caller owns all buffers; the library keeps no pointer after return.
+ */
+#ifndef CHEETAH_HIP_H
+#define CHEETAH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cheetah_ctx cheetah_ctx;
+
+typedef enum {
+    CHEETAH_OK = 0,
+    CHEETAH_ERR_INVALID = -1,   /* null pointer, bad enum value, misaligned device pointer */
+    CHEETAH_ERR_HIP = -2,       /* a HIP runtime call failed (text in cheetah_last_error) */
+    CHEETAH_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    CHEETAH_ERR_SCALAR = -4,    /* scalar outside what the reference's table covers (lookup.rs Q3) */
+    CHEETAH_ERR_NOMEM = -5
+} cheetah_status;
+
+typedef enum { CHEETAH_AFFINE = 0, CHEETAH_PROJECTIVE = 1, CHEETAH_JACOBIAN = 2 } cheetah_form;
+
+/* ---- context -------------------------------------------------------------
+ * Creating a context builds on the device what the reference builds lazily on
+ * first use: BASEPOINT_TABLE (src/constants.rs:21-22, src/lookup.rs:164-173),
+ * the shift point and MINUS_SHIFT_POINT_ARRAY entries (src/constants.rs:43-90). */
+int32_t cheetah_ctx_create(int device_id, cheetah_ctx **out);
+int32_t cheetah_ctx_destroy(cheetah_ctx *ctx);
+/* Issue all following work on an existing hipStream_t (e.g. torch's current stream).
+ * NULL is HIP's default (null) stream, as everywhere in HIP.  A new context starts on a
+ * private non-blocking stream; cheetah_ctx_use_own_stream() goes back to it. */
+int32_t cheetah_ctx_set_stream(cheetah_ctx *ctx, void *hip_stream);
+int32_t cheetah_ctx_use_own_stream(cheetah_ctx *ctx);
+int32_t cheetah_ctx_synchronize(cheetah_ctx *ctx);
+const char *cheetah_last_error(const cheetah_ctx *ctx); /* ctx may be NULL: last create error */
+const char *cheetah_version(void);
+
+/* ---- elementwise Fp6 -----------------------------------------------------
+ * out[i] = a[i] * b[i]           Fp6::mul      src/fp6.rs:651-834
+ * out[i] = a[i]^2                Fp6::square   src/fp6.rs:838-920
+ * out[i] = a[i]^-1, is_some[i]   Fp6::invert   src/fp6.rs:1035-1049 (0 -> out = 0, is_some = 0) */
+int32_t cheetah_fp6_mul_batch(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int32_t cheetah_fp6_square_batch(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int32_t cheetah_fp6_invert_batch(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
+int32_t cheetah_fp6_mul_batch_dev(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int32_t cheetah_fp6_square_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int32_t cheetah_fp6_invert_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
+
+/* ---- batch_normalize -----------------------------------------------------
+ * xy[i], inf[i] = affine form of xyz[i]; identities (z = 0) give (0, 1, inf = 1).
+ * ProjectivePoint::batch_normalize  src/curve/projective.rs:897-930
+ * JacobianPoint::batch_normalize    src/curve/jacobian.rs:886-920
+ * The reference's single sequential inversion chain is re-associated into
+ * per-lane chunks; results are identical because field arithmetic is exact. */
+int32_t cheetah_batch_normalize_projective(cheetah_ctx *ctx, const uint64_t *xyz, uint64_t *xy, uint8_t *inf, size_t n);
+int32_t cheetah_batch_normalize_jacobian(cheetah_ctx *ctx, const uint64_t *xyz, uint64_t *xy, uint8_t *inf, size_t n);
+int32_t cheetah_batch_normalize_projective_dev(cheetah_ctx *ctx, const uint64_t *xyz, uint64_t *xy, uint8_t *inf, size_t n);
+int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx *ctx, const uint64_t *xyz, uint64_t *xy, uint8_t *inf, size_t n);
+
+/* ---- fixed base, constant time --------------------------------------------
+ * out[i] = scalars[i] * G by the reference's comb: &BASEPOINT_TABLE * &Scalar,
+ * BasePointTable::multiply          src/lookup.rs:189-206, src/constants.rs:92-98
+ * out_form = CHEETAH_AFFINE  : out = 12 limbs per point, inf[i] set
+ * out_form = CHEETAH_PROJECTIVE: out = 18 limbs per point = the reference's own
+ *            (X:Y:Z) representative, canonical limbs; inf[i] = (Z == 0); inf may be NULL.
+ * Scalars whose top nibble exceeds 7 are outside LookupTable<8>'s range in the
+ * reference: the call fails with CHEETAH_ERR_SCALAR (host entry
+ * point) or leaves inf[i] = 0xFF for that element (device entry point). */
+int32_t cheetah_mul_by_generator_batch(cheetah_ctx *ctx, const uint8_t *scalars32, uint64_t *out, uint8_t *inf,
+                                       size_t n, int out_form);
+int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx *ctx, const uint8_t *scalars32, uint64_t *out, uint8_t *inf,
+                                           size_t n, int out_form);
+
+/* ---- variable base ---------------------------------------------------------
+ * out[i] = scalars[i] * pts[i]
+ * cheetah_multiply_batch          ProjectivePoint::multiply          src/curve/projective.rs:614-625
+ *                                 (radix-16 signed windows, LookupTable<16>, constant-time table scan)
+ * cheetah_multiply_vartime_batch  ProjectivePoint::multiply_vartime  src/curve/projective.rs:633-662
+ *                                 (width-5 NAF, NafLookupTable<8>, quirk Q1: always 256 doublings)
+ * in_form : CHEETAH_AFFINE (12 limbs; (0, 1) is read as the identity) or CHEETAH_PROJECTIVE (18 limbs).
+ * out_form: as for cheetah_mul_by_generator_batch.  Any 32 bytes are accepted as a scalar, as in the reference. */
+int32_t cheetah_multiply_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
+                               uint64_t *out, uint8_t *inf, size_t n, int out_form);
+int32_t cheetah_multiply_vartime_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
+                                       uint64_t *out, uint8_t *inf, size_t n, int out_form);
+int32_t cheetah_multiply_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
+                                   uint64_t *out, uint8_t *inf, size_t n, int out_form);
+int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form,
+                                           const uint8_t *scalars32, uint64_t *out, uint8_t *inf, size_t n,
+                                           int out_form);
+
+/* ---- precomputed tables (read back for inspection / tests) ----------------
+ * which: 0 = BASEPOINT_TABLE (256 affine points, table-major, src/lookup.rs:136),
+ *        1 = shift point S, -2^4 S, -2^256 S (3 affine points, src/constants.rs:43-90). */
+int32_t cheetah_read_table(cheetah_ctx *ctx, int which, uint64_t *out_xy, size_t max_points);
+
+/* ---- synthetic inputs generated on the device (bench / tests) -------------
+ * The counter-based generator of cheetah_amd/synth.py: no reference counterpart
+ * (the reference draws from OsRng, e.g. benches/fp6.rs:23-29). */
+int32_t cheetah_synth_fp6_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint64_t *out, size_t n);
+int32_t cheetah_synth_scalars_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint8_t *out32, size_t n);
+
+/* ---- diagnostics -----------------------------------------------------------
+ * Unit-level parity hook: applies ONE device function to n operand tuples.
+ * No reference counterpart; used by tests/ to compare each device function
+ * with the oracle.  op codes in cheetah_debug_op. */
+typedef enum {
+    CHEETAH_OP_FP_ADD = 0, CHEETAH_OP_FP_SUB, CHEETAH_OP_FP_MUL, CHEETAH_OP_FP_MUL7, CHEETAH_OP_FP_INVERT,
+    CHEETAH_OP_FP6_ADD = 16, CHEETAH_OP_FP6_SUB, CHEETAH_OP_FP6_MUL3B, CHEETAH_OP_FP6_FROBENIUS,
+    CHEETAH_OP_PROJ_DOUBLE = 32, CHEETAH_OP_PROJ_ADD, CHEETAH_OP_PROJ_ADD_MIXED_UNCHECKED,
+    CHEETAH_OP_MJAC_DOUBLE, CHEETAH_OP_MJAC_ADD_MIXED_UNCHECKED
+} cheetah_debug_op;
+int32_t cheetah_debug_op_dev(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* Measured v_mad_u64_u32 issue rate of this device in 1e12 lane-ops/s (roofline denominator). */
+int32_t cheetah_calibrate_mad_peak(cheetah_ctx *ctx, double *tera_mads_per_s);
+/* Time of the last `_dev` kernel sequence bracketed by HIP events on the ctx stream. */
+int32_t cheetah_timer_start(cheetah_ctx *ctx);
+int32_t cheetah_timer_stop_ms(cheetah_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHEETAH_HIP_H */

@@ -1268,6 +1268,7 @@ static void emit_point(proj r, u64 *out, uint8_t *out_inf, size_t i, int out_for
 static proj load_in_point(const u64 *pts, int in_form, size_t i) {
     if (in_form == 0) { /* affine x|y; (0, 1) is taken as the identity encoding, src/curve/affine.rs:224-230 */
         affine a = affine_load(pts + 12 * i, 0);
+        a.inf = (uint8_t)(fp6_is_zero(a.x) && fp6_eq(a.y, FP6_ONE));
         return proj_from_affine(a);
     }
     return proj_load(pts + 18 * i);

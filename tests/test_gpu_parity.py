@@ -1,0 +1,469 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle (oracle/cheetah_oracle.c), the committed golden fixtures and the
+reference's own known-answer vectors.  Bar: bit-exact on canonical limbs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cheetah_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFFFFFFF00000001
+Q = synth.Q
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cheetah_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint64:
+        return torch.from_numpy(a.view(np.int64)).cuda().view(torch.uint64)
+    return torch.from_numpy(a).cuda()
+
+
+def host(t):
+    import torch
+    if t.dtype == torch.uint64:
+        return t.view(torch.int64).cpu().numpy().view(np.uint64)
+    return t.cpu().numpy()
+
+
+EDGE_FP = [0, 1, 2, 7, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1, 2**32 + 1, 2**63, 2**63 - 1, P - 2**32, 0xFFFFFFFF00000000]
+
+
+def edge_fp6(n, seed):
+    """Seeded Fp6 elements with edge / non-canonical limbs mixed in."""
+    a = synth.fp6_elements(seed, n).copy()
+    rng = np.random.default_rng(seed)
+    for i in range(min(n, 4 * len(EDGE_FP))):
+        a[i, rng.integers(0, 6)] = EDGE_FP[i % len(EDGE_FP)]
+    if n > 70:
+        a[64] = [2**64 - 1] * 6
+        a[65] = [P - 1] * 6
+        a[66] = [0] * 6
+        a[67] = [P] * 6  # non-canonical zero
+        a[68] = [1, 0, 0, 0, 0, 0]
+    return a
+
+
+# ------------------------------------------------------- device functions ----
+
+def test_fp_device_functions(eng):
+    rng = np.random.default_rng(3)
+    vals = EDGE_FP + [int(v) for v in rng.integers(0, 2**64, 2000, dtype=np.uint64)]
+    a = np.array(vals, np.uint64)
+    b = np.array(vals[::-1], np.uint64)
+    b[: len(EDGE_FP) ** 1] = a[: len(EDGE_FP)][::-1]
+    # all edge pairs
+    ea, eb = np.meshgrid(np.array(EDGE_FP, np.uint64), np.array(EDGE_FP, np.uint64))
+    a = np.concatenate([a, ea.ravel()])
+    b = np.concatenate([b, eb.ravel()])
+    A, B = dev(a.reshape(-1, 1)), dev(b.reshape(-1, 1))
+    ai = [int(v) for v in a]
+    bi = [int(v) for v in b]
+    got = host(eng.debug_op(0, A, B, 1)).ravel()
+    assert [int(g) % P for g in got] == [(x + y) % P for x, y in zip(ai, bi)]
+    got = host(eng.debug_op(1, A, B, 1)).ravel()
+    assert [int(g) % P for g in got] == [(x - y) % P for x, y in zip(ai, bi)]
+    got = host(eng.debug_op(2, A, B, 1)).ravel()
+    assert [int(g) % P for g in got] == [(x * y) % P for x, y in zip(ai, bi)]
+    got = host(eng.debug_op(3, A, None, 1)).ravel()
+    assert [int(g) % P for g in got] == [(7 * x) % P for x in ai]
+    got = host(eng.debug_op(4, A, None, 1)).ravel()
+    assert [int(g) % P for g in got] == [pow(x % P, P - 2, P) for x in ai]  # inverse = exp(p-2), src/fp.rs:914-934
+
+
+def test_fp6_device_functions(eng, ora):
+    a, b = edge_fp6(300, 31), edge_fp6(300, 32)[::-1].copy()
+    A, B = dev(a), dev(b)
+    L = ora.lib()
+    for op, name, binary in ((16, "ora_fp6_add", True), (17, "ora_fp6_sub", True), (18, "ora_mul_by_3b", False),
+                             (19, "ora_fp6_frobenius", False)):
+        got = host(eng.debug_op(op, A, B if binary else None, 6)) % np.uint64(P)
+        for i in range(len(a)):
+            want = ora.canon(ora.fp6_binop(name, a[i], b[i]) if binary else ora.fp6_unop(name, a[i]))
+            assert (got[i] == want).all(), (name, i)
+
+
+def _random_points(ora, seed, n, form):
+    """k_i * G as projective (scaled by a random lambda) or affine."""
+    sc = synth.scalars(seed, n)
+    xy, inf = ora.mul_by_generator_batch(sc, 0)
+    if form == "affine":
+        return xy
+    lam = synth.fp6_elements(seed + 1000, n)
+    out = np.zeros((n, 18), np.uint64)
+    for i in range(n):
+        out[i, 0:6] = ora.fp6_binop("ora_fp6_mul", xy[i, 0:6], lam[i])
+        out[i, 6:12] = ora.fp6_binop("ora_fp6_mul", xy[i, 6:12], lam[i])
+        out[i, 12:18] = lam[i]
+    return out
+
+
+def test_point_formulas_projective_parity(eng, ora):
+    """double_unchecked / add / add_mixed_unchecked give the reference's own
+    (X:Y:Z) representative (parity level L2), src/curve/projective.rs:400-610."""
+    L = ora.lib()
+    n = 40
+    p = _random_points(ora, 41, n, "proj")
+    q = _random_points(ora, 43, n, "proj")
+    qa = _random_points(ora, 45, n, "affine")
+    Pd, Qd, QAd = dev(p), dev(q), dev(qa)
+    got_dbl = host(eng.debug_op(32, Pd, None, 18))
+    got_add = host(eng.debug_op(33, Pd, Qd, 18))
+    got_mix = host(eng.debug_op(34, Pd, QAd, 18))
+    out = np.zeros(18, np.uint64)
+    for i in range(n):
+        L.ora_proj_double_unchecked(np.ascontiguousarray(p[i]), out)
+        assert (got_dbl[i] == out % np.uint64(P)).all(), i
+        L.ora_proj_add(np.ascontiguousarray(p[i]), np.ascontiguousarray(q[i]), out)
+        assert (got_add[i] == out % np.uint64(P)).all(), i
+        L.ora_proj_add_mixed_unchecked(np.ascontiguousarray(p[i]), np.ascontiguousarray(qa[i]), 0, out)
+        assert (got_mix[i] == out % np.uint64(P)).all(), i
+    # complete addition on the special cases: P + P, P + (-P), P + O, O + O
+    ident = np.array([0] * 6 + [1] + [0] * 5 + [0] * 6, np.uint64)
+    neg = p.copy()
+    for i in range(n):
+        neg[i, 6:12] = ora.fp6_unop("ora_fp6_neg", p[i, 6:12])
+    cases_a = np.stack([p[0], p[1], p[2], ident])
+    cases_b = np.stack([p[0], neg[1], ident, ident])
+    got = host(eng.debug_op(33, dev(cases_a), dev(cases_b), 18))
+    for i in range(4):
+        L.ora_proj_add(np.ascontiguousarray(cases_a[i]), np.ascontiguousarray(cases_b[i]), out)
+        assert (got[i] == out % np.uint64(P)).all(), i
+
+
+def test_modified_jacobian_formulas(eng, ora):
+    L = ora.lib()
+    n = 24
+    pa = _random_points(ora, 47, n, "affine")
+    qa = _random_points(ora, 49, n, "affine")
+    lam = synth.fp6_elements(51, n)
+    mj = np.zeros((n, 24), np.uint64)
+    for i in range(n):
+        l2 = ora.fp6_unop("ora_fp6_square", lam[i])
+        l3 = ora.fp6_binop("ora_fp6_mul", l2, lam[i])
+        mj[i, 0:6] = ora.fp6_binop("ora_fp6_mul", pa[i, 0:6], l2)
+        mj[i, 6:12] = ora.fp6_binop("ora_fp6_mul", pa[i, 6:12], l3)
+        mj[i, 12:18] = lam[i]
+        mj[i, 18:24] = ora.fp6_unop("ora_fp6_square", l2)
+    got_d = host(eng.debug_op(35, dev(mj), None, 24))
+    got_a = host(eng.debug_op(36, dev(mj), dev(qa), 24))
+    out = np.zeros(24, np.uint64)
+    for i in range(n):
+        L.ora_mjac_double_unchecked(np.ascontiguousarray(mj[i]), out)
+        assert (got_d[i] == out % np.uint64(P)).all(), i
+        L.ora_mjac_add_mixed_unchecked(np.ascontiguousarray(mj[i]), np.ascontiguousarray(qa[i]), 0, out)
+        assert (got_a[i] == out % np.uint64(P)).all(), i
+
+
+# ------------------------------------------------------------ Fp6 batches ----
+
+def test_fp6_reference_kats_on_gpu(eng, kats):
+    k = kats["fp6_mul"]
+    assert list(eng.fp6_mul_batch(np.array([k["a"]], np.uint64), np.array([k["b"]], np.uint64))[0]) == k["out"]
+    k = kats["fp6_square"]
+    assert list(eng.fp6_square_batch(np.array([k["a"]], np.uint64))[0]) == k["out"]
+    k = kats["fp6_invert"]
+    out, some = eng.fp6_invert_batch(np.array([k["a"], [1, 0, 0, 0, 0, 0], [0] * 6, [P, 0, P, 0, 0, P]], np.uint64))
+    assert list(out[0]) == k["out"] and list(out[1]) == [1, 0, 0, 0, 0, 0]
+    assert list(some) == [1, 1, 0, 0] and not out[2].any() and not out[3].any()
+
+
+def test_fp6_golden_model_vectors_on_gpu(eng, model_vectors):
+    rows = model_vectors["fp6"]
+    a = np.array([r["a"] for r in rows], np.uint64)
+    b = np.array([r["b"] for r in rows], np.uint64)
+    assert (eng.fp6_mul_batch(a, b) == np.array([r["mul"] for r in rows], np.uint64)).all()
+    assert (eng.fp6_square_batch(a) == np.array([r["square"] for r in rows], np.uint64)).all()
+    inv, some = eng.fp6_invert_batch(a)
+    assert (inv == np.array([r["invert"] for r in rows], np.uint64)).all() and some.all()
+
+
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 4099])
+def test_fp6_batches_vs_oracle_ragged(eng, ora, n):
+    a, b = edge_fp6(n, 61), edge_fp6(n, 62)[::-1].copy()
+    A, B = dev(a), dev(b)
+    assert (host(eng.fp6_mul_batch(A, B)) == ora.fp6_mul_batch(a, b)).all()
+    assert (host(eng.fp6_square_batch(A)) == ora.fp6_square_batch(a)).all()
+    inv, some = eng.fp6_invert_batch(A)
+    winv, wsome = ora.fp6_invert_batch(a)
+    assert (host(inv) == winv).all() and (host(some) == wsome).all()
+    # host-pointer entry points agree with the device ones
+    assert (eng.fp6_mul_batch(a, b) == host(eng.fp6_mul_batch(A, B))).all()
+
+
+def test_fp6_empty_and_errors(eng):
+    from cheetah_amd import CheetahError
+    z = np.zeros((0, 6), np.uint64)
+    assert eng.fp6_mul_batch(z, z).shape == (0, 6)
+    with pytest.raises(ValueError):
+        eng.fp6_mul_batch(np.zeros((3, 5), np.uint64), np.zeros((3, 5), np.uint64))
+    with pytest.raises(CheetahError):
+        eng._check(eng._lib.cheetah_fp6_mul_batch(eng._h, None, None, None, 4))
+
+
+def test_fp6_mul_full_size_config1(eng, ora):
+    """BASELINE config 1: 2^20 seeded pairs, compared in full with the oracle."""
+    n = 1 << 20
+    A = eng.synth_fp6(1, n, 0)
+    B = eng.synth_fp6(1, n, n)
+    a, b = synth.fp6_elements(1, n, 0), synth.fp6_elements(1, n, n)
+    assert (host(A) == a).all() and (host(B) == b).all()  # device generator == host generator
+    got = host(eng.fp6_mul_batch(A, B))
+    assert (got == ora.fp6_mul_batch(a, b)).all()
+    # size-independent property: (a*b)*a^-1 == b wherever a != 0
+    ainv, some = eng.fp6_invert_batch(A)
+    back = host(eng.fp6_mul_batch(eng.fp6_mul_batch(A, B), ainv))
+    assert host(some).all() and (back == b).all()
+
+
+# ------------------------------------------------------------------ tables ----
+
+def test_tables_vs_oracle(eng, ora, kats):
+    bpt = eng.read_table(0)
+    assert (bpt == ora.table("ora_basepoint_table", 256)).all()
+    sh = eng.read_table(1)
+    ms = ora.table("ora_minus_shift_point_array", 257)
+    assert list(sh[0]) == kats["shift_point"]["x"] + kats["shift_point"]["y"]
+    assert (sh[1] == ms[4]).all() and (sh[2] == ms[256]).all()
+    assert list(bpt[0]) == kats["generator"]["x"] + kats["generator"]["y"]
+    assert list(bpt[1]) == kats["two_g_affine"]["x"] + kats["two_g_affine"]["y"]  # 2G KAT, src/curve/projective.rs:1157-1178
+
+
+# --------------------------------------------------------- batch_normalize ----
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 300, 2049])
+def test_batch_normalize_vs_oracle(eng, ora, n):
+    aff = _random_points(ora, 71, min(n, 64), "affine")
+    aff = np.tile(aff, (n // len(aff) + 1, 1))[:n]
+    lam = synth.fp6_elements(72, n)
+    jac = np.zeros((n, 18), np.uint64)
+    prj = np.zeros((n, 18), np.uint64)
+    for i in range(n):
+        l2 = ora.fp6_unop("ora_fp6_square", lam[i])
+        l3 = ora.fp6_binop("ora_fp6_mul", l2, lam[i])
+        jac[i, 0:6] = ora.fp6_binop("ora_fp6_mul", aff[i, 0:6], l2)
+        jac[i, 6:12] = ora.fp6_binop("ora_fp6_mul", aff[i, 6:12], l3)
+        prj[i, 0:6] = ora.fp6_binop("ora_fp6_mul", aff[i, 0:6], lam[i])
+        prj[i, 6:12] = ora.fp6_binop("ora_fp6_mul", aff[i, 6:12], lam[i])
+        jac[i, 12:18] = lam[i]
+        prj[i, 12:18] = lam[i]
+    # identities sprinkled in (the case the reference's own test never takes),
+    # including runs of them and non-canonical zeros
+    rng = np.random.default_rng(n)
+    idx = set(int(v) for v in rng.integers(0, n, max(1, n // 5)))
+    if n >= 9:
+        idx |= {0, 1, 2, n - 1}
+    for i in idx:
+        jac[i, 12:18] = 0
+        prj[i, 12:18] = [P, 0, 0, P, 0, 0]
+    from cheetah_amd import JACOBIAN, PROJECTIVE
+    wxy, winf = ora.batch_normalize(jac, True)
+    xy, inf = eng.batch_normalize(dev(jac), JACOBIAN)
+    assert (host(xy) == wxy).all() and (host(inf) == winf).all()
+    assert winf.sum() == len(idx)
+    wxy, winf = ora.batch_normalize(prj, False)
+    xy, inf = eng.batch_normalize(dev(prj), PROJECTIVE)
+    assert (host(xy) == wxy).all() and (host(inf) == winf).all()
+    xy, inf = eng.batch_normalize(prj, PROJECTIVE)  # host-pointer entry point
+    assert (xy == wxy).all() and (inf == winf).all()
+
+
+def test_batch_normalize_golden(eng, model_vectors):
+    from cheetah_amd import JACOBIAN, PROJECTIVE
+    rows = model_vectors["normalize"]
+    want = np.array([r["affine"]["xy"] for r in rows], np.uint64)
+    xy, inf = eng.batch_normalize(np.array([r["jacobian"] for r in rows], np.uint64), JACOBIAN)
+    assert (xy == want).all() and not inf.any()
+    xy, inf = eng.batch_normalize(np.array([r["projective"] for r in rows], np.uint64), PROJECTIVE)
+    assert (xy == want).all() and not inf.any()
+    assert eng.batch_normalize(np.zeros((0, 18), np.uint64), JACOBIAN)[0].shape == (0, 12)
+
+
+# -------------------------------------------------------------- fixed base ----
+
+def test_mul_by_generator_golden_and_oracle(eng, ora, model_vectors):
+    from cheetah_amd import AFFINE, PROJECTIVE, CheetahError
+    rows = [r for r in model_vectors["mul_by_generator"] if r["scalar"][31] >> 4 <= 7]
+    sc = np.array([r["scalar"] for r in rows], np.uint8)
+    xy, inf = eng.mul_by_generator_batch(sc, AFFINE)
+    assert [list(v) for v in xy] == [r["out"]["xy"] for r in rows]
+    assert list(inf) == [r["out"]["inf"] for r in rows]
+    # the reference's own projective representative (L2)
+    pr, pinf = eng.mul_by_generator_batch(sc, PROJECTIVE)
+    wpr, wpinf = ora.mul_by_generator_batch(sc, 1)
+    assert (pr == wpr).all() and (pinf == wpinf).all()
+    # out-of-range scalar (top nibble > 7): rejected by the host entry point
+    bad = sc.copy()
+    bad[0, 31] = 0x80
+    with pytest.raises(CheetahError) as ei:
+        eng.mul_by_generator_batch(bad, AFFINE)
+    assert ei.value.code == -4
+
+
+@pytest.mark.parametrize("n", [1, 255, 1000])
+def test_mul_by_generator_seeded_vs_oracle(eng, ora, n):
+    from cheetah_amd import AFFINE, PROJECTIVE
+    sc = synth.scalars(2, n)
+    S = dev(sc)
+    xy, inf = eng.mul_by_generator_batch(S, AFFINE)
+    wxy, winf = ora.mul_by_generator_batch(sc, 0)
+    assert (host(xy) == wxy).all() and (host(inf) == winf).all()
+    pr, _ = eng.mul_by_generator_batch(S, PROJECTIVE)
+    assert (host(pr) == ora.mul_by_generator_batch(sc, 1)[0]).all()
+    assert (host(eng.synth_scalars(2, n)) == sc).all()
+
+
+# ----------------------------------------------------------- variable base ----
+
+def test_multiply_golden(eng, model_vectors):
+    from cheetah_amd import AFFINE
+    rows = model_vectors["multiply"]
+    pts = np.array([r["point"]["xy"] for r in rows], np.uint64)
+    sc = np.array([r["scalar"] for r in rows], np.uint8)
+    want_xy = [r["out"]["xy"] for r in rows]
+    want_inf = [r["out"]["inf"] for r in rows]
+    xy, inf = eng.multiply_batch(pts, sc, AFFINE, AFFINE)
+    assert [list(v) for v in xy] == want_xy and list(inf) == want_inf
+    xy, inf = eng.multiply_vartime_batch(pts, sc, AFFINE, AFFINE)
+    for i, r in enumerate(rows):
+        if int.from_bytes(bytes(sc[i]), "little") < 2**255:  # a set bit 255 is outside the 256-digit NAF
+            assert list(xy[i]) == want_xy[i] and inf[i] == want_inf[i], i
+
+
+@pytest.mark.parametrize("n", [1, 64, 300])
+def test_multiply_vs_oracle_all_forms(eng, ora, n):
+    """ct and vartime ladders; affine and projective inputs; affine output (L1) and
+    the reference's projective representative (L2); multiply == multiply_vartime
+    (src/curve/projective.rs:1339)."""
+    from cheetah_amd import AFFINE, PROJECTIVE
+    sc = synth.scalars(3, n)
+    aff = _random_points(ora, 81, n, "affine")
+    prj = _random_points(ora, 81, n, "proj")
+    # edge scalars and an identity point
+    edge = [0, 1, 2, 15, 16, Q - 1, Q, (1 << 255) - 1]
+    for i, k in enumerate(edge[: n]):
+        sc[i] = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    if n >= 64:
+        aff[20] = [0] * 6 + [1] + [0] * 5       # affine identity encoding
+        prj[20, 12:18] = 0                      # projective identity
+        sc[21] = 255                            # non-canonical 2^256 - 1: needs LookupTable<16>'s entry 16
+    S = dev(sc)
+    for vartime in (False, True):
+        f = eng.multiply_vartime_batch if vartime else eng.multiply_batch
+        for in_form, pts in ((AFFINE, aff), (PROJECTIVE, prj)):
+            Pd = dev(pts)
+            wxy, winf = ora.multiply_batch(pts, in_form, sc, 0, vartime=vartime)
+            xy, inf = f(Pd, S, in_form, AFFINE)
+            assert (host(xy) == wxy).all() and (host(inf) == winf).all(), (vartime, in_form)
+            wpr, wpinf = ora.multiply_batch(pts, in_form, sc, 1, vartime=vartime)
+            pr, pinf = f(Pd, S, in_form, PROJECTIVE)
+            assert (host(pr) == wpr).all() and (host(pinf) == wpinf).all(), (vartime, in_form)
+    # cross-path: ct == vartime on canonical scalars
+    can = np.array([int.from_bytes(bytes(s), "little") < 2**255 for s in sc])
+    a1, i1 = eng.multiply_batch(dev(aff), S, AFFINE, AFFINE)
+    a2, i2 = eng.multiply_vartime_batch(dev(aff), S, AFFINE, AFFINE)
+    assert (host(a1)[can] == host(a2)[can]).all() and (host(i1)[can] == host(i2)[can]).all()
+    # host-pointer entry point
+    xy, inf = eng.multiply_batch(aff, sc, AFFINE, AFFINE)
+    assert (xy == host(a1)).all() and (inf == host(i1)).all()
+
+
+def test_torsion_and_cofactor_kats(eng, kats):
+    """q * G = O through the full vartime ladder (is_torsion_free, src/curve/projective.rs:885-893, :1462);
+    the reference's non-subgroup point is not killed by q but its cofactor multiple is (:1427-1433)."""
+    from cheetah_amd import AFFINE
+    g = kats["generator"]["x"] + kats["generator"]["y"]
+    ns = kats["non_subgroup_point"]["x"] + kats["non_subgroup_point"]["y"]
+    qb, hb = kats["fq_modulus_bytes"], kats["cofactor_bytes"]
+    pts = np.array([g, ns, ns], np.uint64)
+    sc = np.array([qb, qb, hb], np.uint8)
+    for f in (eng.multiply_vartime_batch, eng.multiply_batch):
+        xy, inf = f(pts, sc, AFFINE, AFFINE)
+        assert list(inf) == [1, 0, 0]
+        assert list(xy[0]) == [0] * 6 + [1] + [0] * 5
+        xy2, inf2 = f(np.ascontiguousarray(xy[2:3]), np.array([qb], np.uint8), AFFINE, AFFINE)
+        assert list(inf2) == [1]
+
+
+def test_g_a_b_equals_g_ab_on_gpu(eng):
+    # (g*a)*b == g*(a*b), src/curve/projective.rs:1338, and == BASEPOINT_TABLE path (:1341)
+    from cheetah_amd import AFFINE
+    n = 200
+    a, b = synth.scalars(91, n), synth.scalars(92, n)
+    ab = np.array([list(((int.from_bytes(bytes(x), "little") * int.from_bytes(bytes(y), "little")) % Q).to_bytes(32, "little"))
+                   for x, y in zip(a, b)], np.uint8)
+    ga, _ = eng.mul_by_generator_batch(dev(a), AFFINE)
+    gab, i1 = eng.multiply_batch(ga, dev(b), AFFINE, AFFINE)
+    want, i2 = eng.mul_by_generator_batch(dev(ab), AFFINE)
+    assert (host(gab) == host(want)).all() and (host(i1) == host(i2)).all()
+
+
+# ----------------------------------------- BASELINE-size property checks ----
+
+def test_full_size_configs_2_3_properties(eng, ora):
+    """BASELINE configs 2 and 3 at full size (2^22): a strided sample is compared
+    with the oracle, and the whole batch through size-independent properties:
+    every k_i*G lies in the prime-order subgroup (q * P_i = O for ALL i), and
+    ct == vartime for all i."""
+    import torch
+    from cheetah_amd import AFFINE
+    n = 1 << 22
+    S = eng.synth_scalars(2, n)
+    pts, inf = eng.mul_by_generator_batch(S, AFFINE)             # config 2
+    assert int(inf.sum()) == 0
+    idx = np.arange(0, n, n // 64)
+    sc_s = host(S)[idx]
+    wxy, _ = ora.mul_by_generator_batch(sc_s, 0)
+    assert (host(pts)[idx] == wxy).all()
+    K = eng.synth_scalars(3, n)
+    r_vt, i_vt = eng.multiply_vartime_batch(pts, K, AFFINE, AFFINE)  # config 3
+    r_ct, i_ct = eng.multiply_batch(pts, K, AFFINE, AFFINE)
+    assert torch.equal(r_vt.view(torch.int64), r_ct.view(torch.int64)) and torch.equal(i_vt, i_ct)
+    wxy, winf = ora.multiply_batch(host(pts)[idx], 0, host(K)[idx], 0, vartime=True)
+    assert (host(r_vt)[idx] == wxy).all() and (host(i_vt)[idx] == winf).all()
+    qb = torch.from_numpy(np.frombuffer(Q.to_bytes(32, "little"), np.uint8).copy()).cuda().repeat(n, 1).contiguous()
+    _, i_q = eng.multiply_vartime_batch(r_vt, qb, AFFINE, AFFINE)
+    assert int(i_q.sum()) == n
+
+
+def test_full_size_config4_batch_normalize(eng, ora):
+    """BASELINE config 4 at 2^22 (the 2^24 run is bench.py's): Jacobian points
+    (x l^2, y l^3, l) built on the device from k_i*G, normalised back, must equal
+    the affine points they came from, identities included."""
+    import torch
+    from cheetah_amd import AFFINE, JACOBIAN
+    n = 1 << 22
+    S = eng.synth_scalars(4, n)
+    aff, _ = eng.mul_by_generator_batch(S, AFFINE)
+    lam = eng.synth_fp6(4, n)
+    l2 = eng.fp6_square_batch(lam)
+    l3 = eng.fp6_mul_batch(l2, lam)
+    affi = aff.view(torch.int64)
+    x = eng.fp6_mul_batch(affi[:, 0:6].contiguous(), l2)
+    y = eng.fp6_mul_batch(affi[:, 6:12].contiguous(), l3)
+    jac = torch.cat([x.view(torch.int64), y.view(torch.int64), lam.view(torch.int64)], dim=1).contiguous()
+    ident = torch.arange(0, n, 1000, device="cuda")
+    jac.view(torch.int64)[ident, 12:18] = 0
+    xy, inf = eng.batch_normalize(jac, JACOBIAN)
+    want = affi.clone()
+    want[ident] = torch.tensor([0] * 6 + [1] + [0] * 5, dtype=torch.int64, device="cuda")
+    assert torch.equal(xy.view(torch.int64), want.view(torch.int64))
+    assert int(inf.sum()) == len(ident) and bool(inf[ident].all())
+    idx = np.arange(0, 4096)
+    wxy, winf = ora.batch_normalize(host(jac)[idx], True)
+    assert (host(xy)[idx] == wxy).all() and (host(inf)[idx] == winf).all()
