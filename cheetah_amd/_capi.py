@@ -63,6 +63,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own HIP/HSA runtime under the same SONAME.  Whichever copy is
+        # loaded first serves the whole process, and torch tensors / streams handed to this
+        # library must come from the SAME runtime, so let torch's load first when it is there.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("HIP library missing: %s (run __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)

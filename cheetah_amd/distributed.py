@@ -1,0 +1,63 @@
+"""Sharding of independent scalar multiplications over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The
+reference has nothing distributed; the only exchange step the path has is
+returning results, so there is exactly one kind of collective here: an
+all-gather of the affine results over xGMI.  There is no exchange during
+compute.
+
+Index layout (block-cyclic so that every all-gather writes one contiguous slab
+of the result and needs no staging copy):
+
+    global index g in [0, n):   chunk c = g // (n / C)
+                                rank  r = (g % (n / C)) // s,   s = n / (C * W)
+    rank r computes, for every chunk c, the s consecutive elements starting at
+    c * (n / C) + r * s; the all-gather of chunk c fills [c * n / C, (c + 1) * n / C).
+
+Chunk c's all-gather runs on a second stream while chunk c + 1 computes; only the
+last chunk's gather (1 / C of the traffic) is exposed.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_plan(n, world, chunks):
+    """Returns (s, [(chunk, global_start) ...] for each rank) -- pure index logic."""
+    if n % (world * chunks) != 0:
+        raise ValueError("n = %d must be divisible by world * chunks = %d" % (n, world * chunks))
+    s = n // (world * chunks)
+    per_chunk = n // chunks
+    return s, [[(c, c * per_chunk + r * s) for c in range(chunks)] for r in range(world)]
+
+
+def sharded_apply(compute, n, width, rank, world, chunks, device, dtype=torch.int64, group=None, gather=True):
+    """Runs compute(global_start, count, out_xy_view, out_inf_view) for this rank's
+    blocks and all-gathers the results.  Returns (xy, inf) holding all n results
+    on every rank (gather=True), or with only this rank's blocks filled in.
+
+    compute must enqueue its work on the CURRENT stream of `device`.
+    """
+    s, plan = shard_plan(n, world, chunks)
+    per_chunk = n // chunks
+    xy = torch.empty((n, width), dtype=dtype, device=device)
+    inf = torch.empty((n,), dtype=torch.uint8, device=device)
+    use_cuda = torch.device(device).type == "cuda"
+    comm = torch.cuda.Stream(device=device) if (use_cuda and world > 1 and gather) else None
+    main = torch.cuda.current_stream(device) if use_cuda else None
+    for c, g0 in plan[rank]:
+        compute(g0, s, xy[g0:g0 + s], inf[g0:g0 + s])
+        if world > 1 and gather:
+            lo = c * per_chunk
+            if comm is not None:
+                comm.wait_stream(main)
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(xy[lo:lo + per_chunk], xy[g0:g0 + s], group=group)
+                    dist.all_gather_into_tensor(inf[lo:lo + per_chunk], inf[g0:g0 + s], group=group)
+            else:  # CPU / gloo rehearsal of the same index logic
+                outs = [xy[lo + r * s: lo + (r + 1) * s] for r in range(world)]
+                dist.all_gather(outs, xy[g0:g0 + s].clone(), group=group)
+                outs = [inf[lo + r * s: lo + (r + 1) * s] for r in range(world)]
+                dist.all_gather(outs, inf[g0:g0 + s].clone(), group=group)
+    if comm is not None:
+        main.wait_stream(comm)
+    return xy, inf
