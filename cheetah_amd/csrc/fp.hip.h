@@ -116,28 +116,28 @@ struct Acc3 {
     // src/fp.rs:623-646 applied once to the whole sum:
     //   w = 5-word integer (w4 small);  V = (w1:w0) + eps*w2 - (w3 + 2^32 w4)
     CH_DEV u64 reduce() const {
-        u32 w0 = lo32(c0);
-        // w1..w4 by one carry chain; the t's ride along where their weight allows
-        u64 s1 = (u64)hi32(c0) + lo32(c1);
-        u32 w1 = lo32(s1);
-        u64 s2 = (u64)hi32(c1) + lo32(c2) + hi32(s1);
-        u64 s2b = (u64)lo32(s2) + t0;
-        u32 w2 = lo32(s2b);
-        u64 s3 = (u64)hi32(c2) + t1 + hi32(s2) + hi32(s2b);
-        u32 w3 = lo32(s3);
-        u32 w4 = t2 + hi32(s3);
-        // R = (w1:w0) + eps * w2, carry worth 2^64 = eps (cannot overflow twice)
-        u64 a = mk64(w0, w1);
-        u64 e = ((u64)w2 << 32) - w2;
-        u64 r;
-        bool c = __builtin_uaddll_overflow(a, e, (unsigned long long*)&r);
-        r += c ? FP_EPS : 0ull;
-        // R -= w3 + 2^32 w4, borrow worth -2^64 = -eps (cannot borrow twice)
-        u64 d = mk64(w3, w4);
-        u64 q;
-        bool b = __builtin_usubll_overflow(r, d, (unsigned long long*)&q);
-        q -= b ? FP_EPS : 0ull;
-        return q;
+        // 5-word integer w4..w0 (w4 small) by two short carry chains
+        u32 c;
+        const u32 w0 = lo32(c0);
+        const u32 w1 = __builtin_addc(hi32(c0), lo32(c1), 0u, &c);
+        u32 w2 = __builtin_addc(hi32(c1), lo32(c2), c, &c);
+        u32 w3 = __builtin_addc(hi32(c2), t1, c, &c);
+        u32 w4 = t2 + c;
+        w2 = __builtin_addc(w2, t0, 0u, &c);
+        w3 = __builtin_addc(w3, 0u, c, &c);
+        w4 += c;
+        // R = (w1:w0) + eps * w2, eps * w2 = (w2 << 32) - w2; carry k is worth 2^64 = eps
+        u32 b, k;
+        const u32 elo = __builtin_subc(0u, w2, 0u, &b);
+        const u32 ehi = w2 - b;
+        const u32 r0 = __builtin_addc(w0, elo, 0u, &k);
+        const u32 r1 = __builtin_addc(w1, ehi, k, &k);
+        // Q = R - (w3 + 2^32 w4); borrow b is worth -2^64 = -eps
+        const u32 q0 = __builtin_subc(r0, w3, 0u, &b);
+        const u32 q1 = __builtin_subc(r1, w4, b, &b);
+        // net correction (k - b) * eps; neither case can wrap
+        const u64 corr = (k && !b) ? FP_EPS : ((b && !k) ? (0ull - FP_EPS) : 0ull);
+        return mk64(q0, q1) + corr;
     }
 };
 

@@ -288,7 +288,7 @@ CH_DEV Affine lds_lookup8(const u64* sub /* 8 x 12 limbs in LDS */, int d) {
 }
 
 template <int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK) k_mul_by_generator(const DeviceTables* __restrict__ tab,
+__global__ void __launch_bounds__(BLOCK, 2) k_mul_by_generator(const DeviceTables* __restrict__ tab,
                                                             const u8* __restrict__ scalars, u64* __restrict__ out,
                                                             u8* __restrict__ inf, size_t n) {
     __shared__ u64 s_tab[32 * 8 * 12];
@@ -408,7 +408,7 @@ CH_DEV Proj load_input_point(const u64* pts, size_t i) {
 
 // ProjectivePoint::multiply, src/curve/projective.rs:614-625.
 template <int IN_FORM, int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
+__global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                        const u8* __restrict__ scalars, u64* __restrict__ out,
                                                        u8* __restrict__ inf, size_t n, u64* __restrict__ scratch) {
     __shared__ i8 s_digits[64 * BLOCK];
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(BLOCK) k_multiply_ct(const DeviceTables* __res
 // always 256 doublings and the correction is MINUS_SHIFT_POINT_ARRAY[256].
 // Lanes add only where their own NAF digit is non-zero (divergent by nature).
 template <int IN_FORM, int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK) k_multiply_vartime(const DeviceTables* __restrict__ tab,
+__global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n,
                                                             u64* __restrict__ scratch) {
