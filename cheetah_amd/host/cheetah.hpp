@@ -1,0 +1,160 @@
+// cheetah.hpp -- C++ host-side mirror of the reference crate's API for the batched
+// hot path, on top of the C ABI (include/cheetah_hip.h).
+//
+// The reference is Rust (toposware/cheetah); no Rust toolchain exists in this
+// pipeline, so the host side above the C ABI is written in C++ with the
+// reference's names and argument meaning: cheetah::Fp6, cheetah::AffinePoint,
+// cheetah::ProjectivePoint, cheetah::JacobianPoint, cheetah::BASEPOINT_TABLE.
+// Each batch method is the slice form of the reference method of the same name
+// (file:line cited at the method).  Errors surface as cheetah::Error, mirroring
+// the reference's panics on length mismatch (e.g. batch_normalize's
+// assert_eq!(p.len(), q.len()), src/curve/projective.rs:898).
+//
+// Header-only; link with -lcheetah_hip.  No arithmetic happens on the host.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cheetah_hip.h"
+
+namespace cheetah {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error("cheetah_hip error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+// Plain-old-data images of the reference types, in the layout of the C ABI.
+struct Fp6 {
+    std::array<uint64_t, 6> c;  // Fp6::output_internal(), src/fp6.rs:1126-1135
+};
+struct Scalar {
+    std::array<uint8_t, 32> bytes;  // Scalar::to_bytes(), src/scalar.rs:477-489
+};
+struct AffinePoint {
+    Fp6 x, y;  // infinity flags travel in a separate array (src/curve/affine.rs:37-41)
+};
+struct ProjectivePoint {
+    Fp6 x, y, z;  // src/curve/projective.rs:76-80
+};
+struct JacobianPoint {
+    Fp6 x, y, z;  // src/curve/jacobian.rs:76-80
+};
+static_assert(sizeof(Fp6) == 48 && sizeof(AffinePoint) == 96 && sizeof(ProjectivePoint) == 144, "ABI layout");
+
+// One GPU.  Owns the device tables the reference builds with lazy_static
+// (BASEPOINT_TABLE, shift points; src/constants.rs:18-90).
+class Context {
+public:
+    explicit Context(int device = 0) {
+        int rc = cheetah_ctx_create(device, &h_);
+        if (rc != 0) throw Error(rc, cheetah_last_error(nullptr));
+    }
+    ~Context() {
+        if (h_) cheetah_ctx_destroy(h_);
+    }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    cheetah_ctx* get() const { return h_; }
+    void check(int rc) const {
+        if (rc != 0) throw Error(rc, cheetah_last_error(h_));
+    }
+
+private:
+    cheetah_ctx* h_ = nullptr;
+};
+
+inline const uint64_t* u64p(const void* p) { return static_cast<const uint64_t*>(p); }
+inline uint64_t* u64p(void* p) { return static_cast<uint64_t*>(p); }
+
+// ---- Fp6 --------------------------------------------------------------------
+// out[i] = a[i] * b[i]          Fp6::mul, src/fp6.rs:651-834
+inline std::vector<Fp6> fp6_mul_batch(const Context& ctx, const std::vector<Fp6>& a, const std::vector<Fp6>& b) {
+    if (a.size() != b.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<Fp6> out(a.size());
+    ctx.check(cheetah_fp6_mul_batch(ctx.get(), u64p(a.data()), u64p(b.data()), u64p(out.data()), a.size()));
+    return out;
+}
+// out[i] = a[i]^2               Fp6::square, src/fp6.rs:838-920
+inline std::vector<Fp6> fp6_square_batch(const Context& ctx, const std::vector<Fp6>& a) {
+    std::vector<Fp6> out(a.size());
+    ctx.check(cheetah_fp6_square_batch(ctx.get(), u64p(a.data()), u64p(out.data()), a.size()));
+    return out;
+}
+// out[i] = a[i]^-1, is_some[i]  Fp6::invert -> CtOption, src/fp6.rs:1035-1049
+inline std::vector<Fp6> fp6_invert_batch(const Context& ctx, const std::vector<Fp6>& a, std::vector<uint8_t>& is_some) {
+    std::vector<Fp6> out(a.size());
+    is_some.assign(a.size(), 0);
+    ctx.check(cheetah_fp6_invert_batch(ctx.get(), u64p(a.data()), u64p(out.data()), is_some.data(), a.size()));
+    return out;
+}
+
+// ---- batch_normalize ----------------------------------------------------------
+// ProjectivePoint::batch_normalize(p, q), src/curve/projective.rs:897-930
+inline void batch_normalize(const Context& ctx, const std::vector<ProjectivePoint>& p, std::vector<AffinePoint>& q,
+                            std::vector<uint8_t>& infinity) {
+    q.resize(p.size());
+    infinity.assign(p.size(), 0);
+    ctx.check(cheetah_batch_normalize_projective(ctx.get(), u64p(p.data()), u64p(q.data()), infinity.data(), p.size()));
+}
+// JacobianPoint::batch_normalize(p, q), src/curve/jacobian.rs:886-920
+inline void batch_normalize(const Context& ctx, const std::vector<JacobianPoint>& p, std::vector<AffinePoint>& q,
+                            std::vector<uint8_t>& infinity) {
+    q.resize(p.size());
+    infinity.assign(p.size(), 0);
+    ctx.check(cheetah_batch_normalize_jacobian(ctx.get(), u64p(p.data()), u64p(q.data()), infinity.data(), p.size()));
+}
+
+// ---- ladders --------------------------------------------------------------------
+// &BASEPOINT_TABLE * &scalar, src/constants.rs:92-98 -> BasePointTable::multiply, src/lookup.rs:189-206
+struct BasePointTableT {
+    std::vector<ProjectivePoint> multiply_batch(const Context& ctx, const std::vector<Scalar>& by) const {
+        std::vector<ProjectivePoint> out(by.size());
+        ctx.check(cheetah_mul_by_generator_batch(ctx.get(), by.data()->bytes.data(), u64p(out.data()), nullptr, by.size(),
+                                                 CHEETAH_PROJECTIVE));
+        return out;
+    }
+    std::vector<AffinePoint> multiply_batch_affine(const Context& ctx, const std::vector<Scalar>& by,
+                                                   std::vector<uint8_t>& infinity) const {
+        std::vector<AffinePoint> out(by.size());
+        infinity.assign(by.size(), 0);
+        ctx.check(cheetah_mul_by_generator_batch(ctx.get(), by.data()->bytes.data(), u64p(out.data()), infinity.data(),
+                                                 by.size(), CHEETAH_AFFINE));
+        return out;
+    }
+};
+static const BasePointTableT BASEPOINT_TABLE{};
+
+// ProjectivePoint::multiply(&self, by), src/curve/projective.rs:614-625 (constant time)
+inline std::vector<ProjectivePoint> multiply_batch(const Context& ctx, const std::vector<ProjectivePoint>& p,
+                                                   const std::vector<Scalar>& by) {
+    if (p.size() != by.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<ProjectivePoint> out(p.size());
+    ctx.check(cheetah_multiply_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, by.data()->bytes.data(), u64p(out.data()),
+                                     nullptr, p.size(), CHEETAH_PROJECTIVE));
+    return out;
+}
+// ProjectivePoint::multiply_vartime(&self, by), src/curve/projective.rs:633-662
+inline std::vector<ProjectivePoint> multiply_vartime_batch(const Context& ctx, const std::vector<ProjectivePoint>& p,
+                                                           const std::vector<Scalar>& by) {
+    if (p.size() != by.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<ProjectivePoint> out(p.size());
+    ctx.check(cheetah_multiply_vartime_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, by.data()->bytes.data(),
+                                             u64p(out.data()), nullptr, p.size(), CHEETAH_PROJECTIVE));
+    return out;
+}
+// AffinePoint::multiply(&self, by), src/curve/affine.rs:373-375 (affine in, affine out)
+inline std::vector<AffinePoint> multiply_batch(const Context& ctx, const std::vector<AffinePoint>& p,
+                                               const std::vector<Scalar>& by, std::vector<uint8_t>& infinity) {
+    if (p.size() != by.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<AffinePoint> out(p.size());
+    infinity.assign(p.size(), 0);
+    ctx.check(cheetah_multiply_batch(ctx.get(), u64p(p.data()), CHEETAH_AFFINE, by.data()->bytes.data(), u64p(out.data()),
+                                     infinity.data(), p.size(), CHEETAH_AFFINE));
+    return out;
+}
+
+}  // namespace cheetah

@@ -59,3 +59,16 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in src.replace("no oracle", ""), fn
+
+
+def test_cpp_host_api_compiles_and_fails_loudly_without_gpu():
+    """cheetah_amd/host/cheetah.hpp (the C++ mirror of the reference API) builds
+    against the C ABI; without a GPU the program reports the error and exits 2."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "tests", "cpp", "host_api_test")
+    assert os.path.exists(exe), "build first (__graft_entry__.build())"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no HIP device" in r.stdout

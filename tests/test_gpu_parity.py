@@ -467,3 +467,12 @@ def test_full_size_config4_batch_normalize(eng, ora):
     idx = np.arange(0, 4096)
     wxy, winf = ora.batch_normalize(host(jac)[idx], True)
     assert (host(xy)[idx] == wxy).all() and (host(inf)[idx] == winf).all()
+
+
+def test_cpp_host_api_on_gpu():
+    """The C++ host API (cheetah_amd/host/cheetah.hpp) against the reference's KATs."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "host_api_test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_api_test: ok" in r.stdout
