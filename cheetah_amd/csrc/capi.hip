@@ -104,7 +104,7 @@ extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
     CREATE_TRY(hipMalloc(&seeds, 24 * sizeof(u64)));
     CREATE_TRY(hipMemcpyAsync(seeds, GENERATOR_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyAsync(seeds + 12, SHIFT_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(64), 0, ctx->stream, ctx->tables, seeds, seeds + 12);
+    hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(BUILD_TABLES_THREADS), 0, ctx->stream, ctx->tables, seeds, seeds + 12);
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
     CREATE_TRY(hipFree(seeds));
@@ -222,9 +222,16 @@ extern "C" int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx* ctx, const 
 
 // ------------------------------------------------------------- ladders -----
 
+// Which reference ladder a (in_form, out_form) pair names:
+//   PROJECTIVE on either side -> ProjectivePoint::multiply*           (projective accumulator)
+//   otherwise                 -> JacobianPoint / AffinePoint::multiply* (modified-Jacobian accumulator;
+//                                AffinePoint's methods delegate to JacobianPoint's, src/curve/affine.rs:373-386)
+// PROJECTIVE <-> JACOBIAN has no counterpart in the reference and is rejected.
 static int32_t check_forms(cheetah_ctx* ctx, int in_form, int out_form) {
-    if (in_form != CHEETAH_AFFINE && in_form != CHEETAH_PROJECTIVE) return fail(ctx, CHEETAH_ERR_INVALID, "in_form must be AFFINE or PROJECTIVE");
-    if (out_form != CHEETAH_AFFINE && out_form != CHEETAH_PROJECTIVE) return fail(ctx, CHEETAH_ERR_INVALID, "out_form must be AFFINE or PROJECTIVE");
+    if (in_form < CHEETAH_AFFINE || in_form > CHEETAH_JACOBIAN) return fail(ctx, CHEETAH_ERR_INVALID, "in_form must be AFFINE, PROJECTIVE or JACOBIAN");
+    if (out_form < CHEETAH_AFFINE || out_form > CHEETAH_JACOBIAN) return fail(ctx, CHEETAH_ERR_INVALID, "out_form must be AFFINE, PROJECTIVE or JACOBIAN");
+    if ((in_form == CHEETAH_PROJECTIVE && out_form == CHEETAH_JACOBIAN) || (in_form == CHEETAH_JACOBIAN && out_form == CHEETAH_PROJECTIVE))
+        return fail(ctx, CHEETAH_ERR_INVALID, "PROJECTIVE and JACOBIAN cannot be mixed in one call");
     return CHEETAH_OK;
 }
 
@@ -238,8 +245,10 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
     int grid = lane_grid(ctx, n, 2);
     if (out_form == CHEETAH_AFFINE)
         hipLaunchKernelGGL((k_mul_by_generator<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
-    else
+    else if (out_form == CHEETAH_PROJECTIVE)
         hipLaunchKernelGGL((k_mul_by_generator<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
+    else
+        hipLaunchKernelGGL((k_mul_by_generator_lookup<2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }
@@ -254,24 +263,24 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     int grid = lane_grid(ctx, n, 2);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
-#define LAUNCH(KERN, I, O) \
-    hipLaunchKernelGGL((KERN<I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts, scalars32, out, inf, n, ctx->scratch)
-    const int sel = (in_form == CHEETAH_PROJECTIVE ? 2 : 0) | (out_form == CHEETAH_PROJECTIVE ? 1 : 0);
-    if (VARTIME) {
-        switch (sel) {
-            case 0: LAUNCH(k_multiply_vartime, 0, 0); break;
-            case 1: LAUNCH(k_multiply_vartime, 0, 1); break;
-            case 2: LAUNCH(k_multiply_vartime, 1, 0); break;
-            default: LAUNCH(k_multiply_vartime, 1, 1); break;
-        }
-    } else {
-        switch (sel) {
-            case 0: LAUNCH(k_multiply_ct, 0, 0); break;
-            case 1: LAUNCH(k_multiply_ct, 0, 1); break;
-            case 2: LAUNCH(k_multiply_ct, 1, 0); break;
-            default: LAUNCH(k_multiply_ct, 1, 1); break;
-        }
+#define LAUNCH(KERN, A, I, O) \
+    hipLaunchKernelGGL((KERN<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts, scalars32, out, inf, n, ctx->scratch)
+#define DISPATCH(KERN)                                         \
+    switch (in_form * 3 + out_form) {                          \
+        case 0: LAUNCH(KERN, MJac, 0, 0); break; /* A -> A */ \
+        case 1: LAUNCH(KERN, Proj, 0, 1); break; /* A -> P */ \
+        case 2: LAUNCH(KERN, MJac, 0, 2); break; /* A -> J */ \
+        case 3: LAUNCH(KERN, Proj, 1, 0); break; /* P -> A */ \
+        case 4: LAUNCH(KERN, Proj, 1, 1); break; /* P -> P */ \
+        case 6: LAUNCH(KERN, MJac, 2, 0); break; /* J -> A */ \
+        default: LAUNCH(KERN, MJac, 2, 2); break; /* J -> J */ \
     }
+    if (VARTIME) {
+        DISPATCH(k_multiply_vartime)
+    } else {
+        DISPATCH(k_multiply_ct)
+    }
+#undef DISPATCH
 #undef LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
@@ -378,10 +387,11 @@ extern "C" int32_t cheetah_mul_by_generator_batch(cheetah_ctx* ctx, const uint8_
     if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
     if (n == 0) return CHEETAH_OK;
     if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    for (size_t i = 0; i < n; i++)
-        if ((scalars32[32 * i + 31] >> 4) > 7)
-            return fail(ctx, CHEETAH_ERR_SCALAR, "scalar with top nibble > 7: outside BasePointTable's LookupTable<8> range");
-    const size_t w = out_form == CHEETAH_AFFINE ? 96 : 144;
+    if (out_form != CHEETAH_JACOBIAN)  // BASEPOINT_LOOKUP's LookupTable<128> covers every radix-256 digit
+        for (size_t i = 0; i < n; i++)
+            if ((scalars32[32 * i + 31] >> 4) > 7)
+                return fail(ctx, CHEETAH_ERR_SCALAR, "scalar with top nibble > 7: outside BasePointTable's LookupTable<8> range");
+    const size_t w = out_form == CHEETAH_AFFINE ? 96 : 144;  // projective and Jacobian: x | y | z
     DevBuf dsc, dout, dinf;
     HIP_TRY(ctx, dsc.alloc(n * 32));
     HIP_TRY(ctx, dout.alloc(n * w));
@@ -437,6 +447,9 @@ extern "C" int32_t cheetah_read_table(cheetah_ctx* ctx, int which, uint64_t* out
     } else if (which == 1) {
         off = offsetof(DeviceTables, shift);
         pts = 3;
+    } else if (which == 2) {
+        off = offsetof(DeviceTables, basepoint_lookup);
+        pts = 128;
     } else {
         return fail(ctx, CHEETAH_ERR_INVALID, "unknown table");
     }

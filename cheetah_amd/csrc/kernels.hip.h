@@ -17,6 +17,7 @@ struct DeviceTables {
     u64 shift[12];               // S                                                src/constants.rs:43-61
     u64 minus_shift_4[12];       // MINUS_SHIFT_POINT_ARRAY[4]   = -2^4 S            src/constants.rs:76-90
     u64 minus_shift_256[12];     // MINUS_SHIFT_POINT_ARRAY[256] = -2^256 S
+    u64 basepoint_lookup[128 * 12];  // BASEPOINT_LOOKUP: LookupTable<128> = [G .. 128 G], x|y  src/constants.rs:26-27
 };
 
 // ---- AoS <-> register helpers --------------------------------------------
@@ -63,13 +64,44 @@ CH_DEV void emit_point(u64* out, u8* inf, size_t i, const Proj& p) {
     else
         store_proj(out, inf, i, p);
 }
+// Modified-Jacobian accumulator: out_form 0 = AffinePoint::from(&JacobianPoint)
+// (src/curve/affine.rs:86-101), 2 = the Jacobian representative (x, y, z) as is
+// (From<ModifiedJacobianPoint> for JacobianPoint drops z^4, src/curve/jacobian.rs:118-126).
+template <int OUT_FORM>
+CH_DEV void emit_point(u64* out, u8* inf, size_t i, const MJac& p) {
+    Proj j;
+    j.x = p.x;
+    j.y = p.y;
+    j.z = p.z;
+    if (OUT_FORM == 0)
+        store_affine(out, inf, i, affine_from_jac(j));
+    else
+        store_proj(out, inf, i, j);
+}
+
+// Ladder accumulators: the two coordinate systems the reference runs its ladders
+// in.  Proj = ProjectivePoint (src/curve/projective.rs:400-443, :576-610), MJac =
+// ModifiedJacobianPoint (src/curve/jacobian.rs:1094-1128, :1146-1186).
+template <class ACC> struct Ladder;
+template <> struct Ladder<Proj> {
+    static CH_DEV Proj from_affine(const Affine& a) { return proj_from_affine(a); }
+    static CH_DEV Proj dbl(const Proj& p) { return proj_double_unchecked(p); }
+    static CH_DEV Proj add(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
+};
+template <> struct Ladder<MJac> {
+    static CH_DEV MJac from_affine(const Affine& a) { return mjac_from_affine(a); }
+    static CH_DEV MJac dbl(const MJac& p) { return mjac_double_unchecked(p); }
+    static CH_DEV MJac add(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked(p, q); }
+};
 
 // ---------------------------------------------------------------------------
 // Table construction (context creation).  Thread t < 32 builds LookupTable<8> of
 // 256^t G (src/lookup.rs:164-173, :25-37); thread 32 builds -2^4 S and -2^256 S
-// (src/constants.rs:80-90).  Entries are affine, hence independent of how they
-// were computed.
-__global__ void __launch_bounds__(64) k_build_tables(DeviceTables* tab, const u64* gen_xy, const u64* shift_xy) {
+// (src/constants.rs:80-90); thread 64 + e builds entry (e + 1) G of
+// BASEPOINT_LOOKUP (src/constants.rs:26-27).  Entries are affine, hence
+// independent of how they were computed.
+constexpr int BUILD_TABLES_THREADS = 192;
+__global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTables* tab, const u64* gen_xy, const u64* shift_xy) {
     const int t = threadIdx.x;
     if (t < 32) {
         Proj base = proj_from_affine(load_affine(gen_xy));
@@ -90,6 +122,16 @@ __global__ void __launch_bounds__(64) k_build_tables(DeviceTables* tab, const u6
             if (i == 4) store_affine(tab->minus_shift_4, nullptr, 0, affine_from_proj(cur));
         }
         store_affine(tab->minus_shift_256, nullptr, 0, affine_from_proj(cur));
+    } else if (t >= 64) {
+        const int m = t - 63;  // 1 .. 128, by left-to-right double-and-add with the complete formulas
+        const Proj g = proj_from_affine(load_affine(gen_xy));
+        Proj acc = proj_identity();
+        for (int b = 7; b >= 0; b--) {
+            acc = proj_double(acc);
+            Proj sum = proj_add(acc, g);
+            if ((m >> b) & 1) acc = sum;
+        }
+        store_affine(tab->basepoint_lookup, nullptr, (size_t)(m - 1), affine_from_proj(acc));
     }
 }
 
@@ -320,6 +362,77 @@ __global__ void __launch_bounds__(BLOCK, 2) k_mul_by_generator(const DeviceTable
 }
 
 // ---------------------------------------------------------------------------
+// Fixed base through BASEPOINT_LOOKUP (`&BASEPOINT_LOOKUP * &Scalar`,
+// src/constants.rs:102-135): radix-256 signed digits (src/scalar.rs:555-576), a
+// modified-Jacobian accumulator, 32 x (8 doublings + constant-time scan of the
+// 128-entry table + mixed addition).  3.1x the field multiplications of the
+// BASEPOINT_TABLE comb; kept because it is the reference's Jacobian fixed-base
+// operator and returns its (X, Y, Z).
+CH_DEV void recode_radix256(const u64 k[4], i8* digits /* [32][BLOCK] */, int t) {
+    int carry = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        u64 v = k[w];
+        for (int j = 0; j < 8; j++) {
+            const int i = 8 * w + j;
+            int d = (int)(v & 0xff) + carry;
+            v >>= 8;
+            if (i < 31) {
+                carry = (d + 128) >> 8;
+                d -= carry << 8;
+            }
+            digits[i * BLOCK + t] = (i8)d;  // digit 31 wraps like the reference's `as i8` (128 -> -128)
+        }
+    }
+}
+
+CH_DEV Affine lds_lookup128(const u64* tabl /* 128 x 12 limbs in LDS */, int d) {
+    const int neg = d < 0;
+    const int dabs = neg ? -d : d;  // -128 -> 128: entry 128, negated (src/lookup.rs:86-98)
+    Affine t = affine_identity();
+    for (int j = 1; j <= 128; j++) {
+        const bool hit = (dabs == j);
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            u64 vx = tabl[(j - 1) * 12 + l], vy = tabl[(j - 1) * 12 + 6 + l];
+            t.x.c[l] = hit ? vx : t.x.c[l];
+            t.y.c[l] = hit ? vy : t.y.c[l];
+        }
+        t.inf = hit ? false : t.inf;
+    }
+    return affine_cond_neg(t, neg);
+}
+
+template <int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK, 2) k_mul_by_generator_lookup(const DeviceTables* __restrict__ tab,
+                                                                   const u8* __restrict__ scalars, u64* __restrict__ out,
+                                                                   u8* __restrict__ inf, size_t n) {
+    __shared__ u64 s_tab[128 * 12];
+    __shared__ i8 s_digits[32 * BLOCK];
+    const int t = threadIdx.x;
+    for (int w = t; w < 128 * 12; w += BLOCK) s_tab[w] = tab->basepoint_lookup[w];
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t nround = (n + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i = round * BLOCK + t;
+        const bool active = i < n;
+        u64 k[4];
+        load_scalar(scalars, active ? i : n - 1, k);
+        __syncthreads();
+        recode_radix256(k, s_digits, t);
+        __syncthreads();
+        MJac acc = mjac_from_affine(shift);
+        for (int j = 31; j >= 0; j--) {
+            for (int r = 0; r < 8; r++) acc = mjac_double_unchecked(acc);
+            acc = mjac_add_mixed_unchecked(acc, lds_lookup128(s_tab, s_digits[j * BLOCK + t]));
+        }
+        acc = mjac_add_mixed_unchecked(acc, mshift);
+        if (active) emit_point<OUT_FORM>(out, inf, i, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Variable base (configs 3 and 5).  Each lane owns a window table in global
 // scratch, laid out [entry][limb][lane] per workgroup so that every access is a
 // coalesced 512 B per wave.
@@ -394,6 +507,11 @@ CH_DEV Affine scan_lookup(const u64* s_tab, int n_entries, u32 ident, int d, int
     return affine_cond_neg(r, neg);
 }
 
+// The point whose multiples fill the window table, as a projective point:
+//   affine input     ProjectivePoint::from(&AffinePoint)              src/curve/projective.rs:102-110
+//   projective input as is
+//   Jacobian input   LookupTable::from(&JacobianPoint) normalises first: AffinePoint::from(p),
+//                    one Fp6 inversion                                src/lookup.rs:45-49, src/curve/affine.rs:86-101
 template <int IN_FORM>
 CH_DEV Proj load_input_point(const u64* pts, size_t i) {
     if (IN_FORM == 0) {
@@ -403,11 +521,15 @@ CH_DEV Proj load_input_point(const u64* pts, size_t i) {
                 fp_is_zero(a.y.c[3]) && fp_is_zero(a.y.c[4]) && fp_is_zero(a.y.c[5]);
         return proj_from_affine(a);
     }
+    if (IN_FORM == 2) return proj_from_affine(affine_from_jac(load_proj(pts + 18 * i)));
     return load_proj(pts + 18 * i);
 }
 
-// ProjectivePoint::multiply, src/curve/projective.rs:614-625.
-template <int IN_FORM, int OUT_FORM>
+// ProjectivePoint::multiply (ACC = Proj, src/curve/projective.rs:614-625) and
+// JacobianPoint::multiply / AffinePoint::multiply (ACC = MJac,
+// src/curve/jacobian.rs:599-611, src/curve/affine.rs:373-375): same loop, the
+// accumulator type is the only difference.
+template <class ACC, int IN_FORM, int OUT_FORM>
 __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                        const u8* __restrict__ scalars, u64* __restrict__ out,
                                                        u8* __restrict__ inf, size_t n, u64* __restrict__ scratch) {
@@ -434,21 +556,23 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __
         const int n_entries = __any(wide) ? 16 : 8;
         const Proj p = load_input_point<IN_FORM>(pts, ii);
         const u32 ident = build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
-        Proj acc = proj_from_affine(shift);
+        ACC acc = Ladder<ACC>::from_affine(shift);
         for (int j = 63; j >= 0; j--) {
-            for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
-            acc = proj_add_mixed_unchecked(acc, scan_lookup(s_tab, n_entries, ident, s_digits[j * BLOCK + t], t));
+            for (int r = 0; r < 4; r++) acc = Ladder<ACC>::dbl(acc);
+            acc = Ladder<ACC>::add(acc, scan_lookup(s_tab, n_entries, ident, s_digits[j * BLOCK + t], t));
         }
-        acc = proj_add_mixed_unchecked(acc, mshift);
+        acc = Ladder<ACC>::add(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
 }
 
-// ProjectivePoint::multiply_vartime, src/curve/projective.rs:633-662, with its
+// ProjectivePoint::multiply_vartime (ACC = Proj, src/curve/projective.rs:633-662)
+// and JacobianPoint / AffinePoint::multiply_vartime (ACC = MJac,
+// src/curve/jacobian.rs:619-649, src/curve/affine.rs:384-386), with their
 // quirk Q1: the "skip unset digits" loop never moves i off 255, so there are
 // always 256 doublings and the correction is MINUS_SHIFT_POINT_ARRAY[256].
 // Lanes add only where their own NAF digit is non-zero (divergent by nature).
-template <int IN_FORM, int OUT_FORM>
+template <class ACC, int IN_FORM, int OUT_FORM>
 __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n,
@@ -472,9 +596,9 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
         __syncthreads();
         const Proj p = load_input_point<IN_FORM>(pts, ii);
         const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
-        Proj acc = proj_from_affine(shift);
+        ACC acc = Ladder<ACC>::from_affine(shift);
         for (int j = 255; j >= 0; j--) {
-            acc = proj_double_unchecked(acc);
+            acc = Ladder<ACC>::dbl(acc);
             const int d = s_naf[j * BLOCK + t];
             if (d != 0) {
                 const int e = (d < 0 ? -d : d) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
@@ -482,10 +606,10 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
                 q.x = sc_load(s_tab, e, 0, t, 12);
                 q.y = sc_load(s_tab, e, 6, t, 12);
                 q.inf = (ident >> e) & 1;
-                acc = proj_add_mixed_unchecked(acc, affine_cond_neg(q, d < 0));
+                acc = Ladder<ACC>::add(acc, affine_cond_neg(q, d < 0));
             }
         }
-        acc = proj_add_mixed_unchecked(acc, mshift);
+        acc = Ladder<ACC>::add(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
 }

@@ -159,13 +159,14 @@ class Engine:
     def _out_width(out_form):
         if out_form == AFFINE:
             return 12
-        if out_form == PROJECTIVE:
+        if out_form in (PROJECTIVE, JACOBIAN):
             return 18
-        raise ValueError("out_form must be AFFINE or PROJECTIVE")
+        raise ValueError("form must be AFFINE, PROJECTIVE or JACOBIAN")
 
     def mul_by_generator_batch(self, scalars, out_form=AFFINE, out=None, inf=None):
-        """out[i] = scalars[i] * G   (&BASEPOINT_TABLE * &Scalar = BasePointTable::multiply,
-        src/lookup.rs:189-206, src/constants.rs:92-98)"""
+        """out[i] = scalars[i] * G.  AFFINE / PROJECTIVE: &BASEPOINT_TABLE * &Scalar =
+        BasePointTable::multiply (src/lookup.rs:189-206, src/constants.rs:92-98);
+        JACOBIAN: &BASEPOINT_LOOKUP * &Scalar (src/constants.rs:102-135)."""
         w = self._out_width(out_form)
         if _is_torch(scalars):
             s = self._dev(scalars, 1, 32)
@@ -207,16 +208,20 @@ class Engine:
         return out, inf
 
     def multiply_batch(self, pts, scalars, in_form=AFFINE, out_form=AFFINE, out=None, inf=None):
-        """out[i] = scalars[i] * pts[i], constant time   (ProjectivePoint::multiply, src/curve/projective.rs:614-625)"""
+        """out[i] = scalars[i] * pts[i], constant time.  PROJECTIVE on either side:
+        ProjectivePoint::multiply (src/curve/projective.rs:614-625); otherwise JacobianPoint::multiply
+        (src/curve/jacobian.rs:599-611), which is also what AffinePoint::multiply runs (src/curve/affine.rs:373-375)."""
         return self._multiply(False, pts, scalars, in_form, out_form, out, inf)
 
     def multiply_vartime_batch(self, pts, scalars, in_form=AFFINE, out_form=AFFINE, out=None, inf=None):
-        """out[i] = scalars[i] * pts[i], variable time   (ProjectivePoint::multiply_vartime, src/curve/projective.rs:633-662)"""
+        """out[i] = scalars[i] * pts[i], variable time.  ProjectivePoint::multiply_vartime
+        (src/curve/projective.rs:633-662) or JacobianPoint / AffinePoint::multiply_vartime
+        (src/curve/jacobian.rs:619-649), chosen by the forms as in multiply_batch."""
         return self._multiply(True, pts, scalars, in_form, out_form, out, inf)
 
     # -- tables / synthetic inputs / diagnostics -------------------------------------
     def read_table(self, which):
-        n = 256 if which == 0 else 3
+        n = {0: 256, 1: 3, 2: 128}[which]
         out = np.empty((n, 12), np.uint64)
         self._check(self._lib.cheetah_read_table(self._h, which, out.ctypes.data, n))
         return out
@@ -301,6 +306,14 @@ class JacobianPoint:
     def batch_normalize(p, engine=None):
         return (engine or default_engine()).batch_normalize(p, JACOBIAN)
 
+    @staticmethod
+    def multiply_batch(points, scalars, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_batch(points, scalars, in_form, out_form)
+
+    @staticmethod
+    def multiply_vartime_batch(points, scalars, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_vartime_batch(points, scalars, in_form, out_form)
+
 
 class AffinePoint:
     @staticmethod
@@ -320,4 +333,13 @@ class _BasePointTable:
         return (engine or default_engine()).mul_by_generator_batch(scalars, out_form)
 
 
+class _BasePointLookup:
+    """`&BASEPOINT_LOOKUP * &Scalar` (src/constants.rs:102-135) over a batch: Jacobian results."""
+
+    @staticmethod
+    def multiply_batch(scalars, engine=None):
+        return (engine or default_engine()).mul_by_generator_batch(scalars, JACOBIAN)
+
+
 BASEPOINT_TABLE = _BasePointTable()
+BASEPOINT_LOOKUP = _BasePointLookup()

@@ -51,7 +51,8 @@ typedef enum { CHEETAH_AFFINE = 0, CHEETAH_PROJECTIVE = 1, CHEETAH_JACOBIAN = 2 
 /* ---- context -------------------------------------------------------------
  * Creating a context builds on the device what the reference builds lazily on
  * first use: BASEPOINT_TABLE (src/constants.rs:21-22, src/lookup.rs:164-173),
- * the shift point and MINUS_SHIFT_POINT_ARRAY entries (src/constants.rs:43-90). */
+ * BASEPOINT_LOOKUP (src/constants.rs:26-27), the shift point and the
+ * MINUS_SHIFT_POINT_ARRAY entries the ladders use (src/constants.rs:43-90). */
 int32_t cheetah_ctx_create(int device_id, cheetah_ctx **out);
 int32_t cheetah_ctx_destroy(cheetah_ctx *ctx);
 /* Issue all following work on an existing hipStream_t (e.g. torch's current stream).
@@ -86,14 +87,18 @@ int32_t cheetah_batch_normalize_projective_dev(cheetah_ctx *ctx, const uint64_t 
 int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx *ctx, const uint64_t *xyz, uint64_t *xy, uint8_t *inf, size_t n);
 
 /* ---- fixed base, constant time --------------------------------------------
- * out[i] = scalars[i] * G by the reference's comb: &BASEPOINT_TABLE * &Scalar,
- * BasePointTable::multiply          src/lookup.rs:189-206, src/constants.rs:92-98
- * out_form = CHEETAH_AFFINE  : out = 12 limbs per point, inf[i] set
- * out_form = CHEETAH_PROJECTIVE: out = 18 limbs per point = the reference's own
- *            (X:Y:Z) representative, canonical limbs; inf[i] = (Z == 0); inf may be NULL.
- * Scalars whose top nibble exceeds 7 are outside LookupTable<8>'s range in the
- * reference: the call fails with CHEETAH_ERR_SCALAR (host entry
- * point) or leaves inf[i] = 0xFF for that element (device entry point). */
+ * out[i] = scalars[i] * G.
+ * out_form = CHEETAH_AFFINE    : &BASEPOINT_TABLE * &Scalar = BasePointTable::multiply
+ *                                (src/lookup.rs:189-206, src/constants.rs:92-98), normalised;
+ *                                out = 12 limbs per point, inf[i] set
+ * out_form = CHEETAH_PROJECTIVE: the same comb; out = 18 limbs per point = the reference's own
+ *                                (X:Y:Z) representative, canonical limbs; inf[i] = (Z == 0); inf may be NULL
+ * out_form = CHEETAH_JACOBIAN  : &BASEPOINT_LOOKUP * &Scalar (src/constants.rs:102-135): radix-256
+ *                                digits, LookupTable<128>, modified-Jacobian accumulator; out = 18
+ *                                limbs = the reference's Jacobian (X, Y, Z); inf as for PROJECTIVE
+ * BASEPOINT_TABLE: scalars whose top nibble exceeds 7 are outside LookupTable<8>'s range in the
+ * reference: the call fails with CHEETAH_ERR_SCALAR (host entry point) or leaves
+ * inf[i] = 0xFF for that element (device entry point).  BASEPOINT_LOOKUP takes any 32 bytes. */
 int32_t cheetah_mul_by_generator_batch(cheetah_ctx *ctx, const uint8_t *scalars32, uint64_t *out, uint8_t *inf,
                                        size_t n, int out_form);
 int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx *ctx, const uint8_t *scalars32, uint64_t *out, uint8_t *inf,
@@ -101,12 +106,19 @@ int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx *ctx, const uint8_t *scal
 
 /* ---- variable base ---------------------------------------------------------
  * out[i] = scalars[i] * pts[i]
- * cheetah_multiply_batch          ProjectivePoint::multiply          src/curve/projective.rs:614-625
- *                                 (radix-16 signed windows, LookupTable<16>, constant-time table scan)
- * cheetah_multiply_vartime_batch  ProjectivePoint::multiply_vartime  src/curve/projective.rs:633-662
- *                                 (width-5 NAF, NafLookupTable<8>, quirk Q1: always 256 doublings)
- * in_form : CHEETAH_AFFINE (12 limbs; (0, 1) is read as the identity) or CHEETAH_PROJECTIVE (18 limbs).
- * out_form: as for cheetah_mul_by_generator_batch.  Any 32 bytes are accepted as a scalar, as in the reference. */
+ * cheetah_multiply_batch          radix-16 signed windows, LookupTable<16>, constant-time table scan
+ * cheetah_multiply_vartime_batch  width-5 NAF, NafLookupTable<8>, quirk Q1: always 256 doublings
+ * The (in_form, out_form) pair names the reference method, as its own types do:
+ *   PROJECTIVE on either side : ProjectivePoint::multiply / multiply_vartime  src/curve/projective.rs:614-662
+ *   JACOBIAN on either side   : JacobianPoint::multiply / multiply_vartime    src/curve/jacobian.rs:599-649
+ *   AFFINE -> AFFINE          : AffinePoint::multiply / multiply_vartime, which delegate to
+ *                               JacobianPoint's (src/curve/affine.rs:373-386)
+ *   PROJECTIVE with JACOBIAN  : no such method in the reference; CHEETAH_ERR_INVALID
+ * in_form : CHEETAH_AFFINE (12 limbs; (0, 1) is read as the identity), CHEETAH_PROJECTIVE or
+ *           CHEETAH_JACOBIAN (18 limbs).
+ * out_form: AFFINE = 12 limbs + inf; PROJECTIVE / JACOBIAN = the reference's own (X, Y, Z) of that
+ *           method, 18 canonical limbs, inf[i] = (Z == 0), inf may be NULL.
+ * Any 32 bytes are accepted as a scalar, as in the reference. */
 int32_t cheetah_multiply_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
                                uint64_t *out, uint8_t *inf, size_t n, int out_form);
 int32_t cheetah_multiply_vartime_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
@@ -119,7 +131,8 @@ int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx *ctx, const uint64_t *pts
 
 /* ---- precomputed tables (read back for inspection / tests) ----------------
  * which: 0 = BASEPOINT_TABLE (256 affine points, table-major, src/lookup.rs:136),
- *        1 = shift point S, -2^4 S, -2^256 S (3 affine points, src/constants.rs:43-90). */
+ *        1 = shift point S, -2^4 S, -2^256 S (3 affine points, src/constants.rs:43-90),
+ *        2 = BASEPOINT_LOOKUP = [G .. 128 G] (128 affine points, src/constants.rs:26-27). */
 int32_t cheetah_read_table(cheetah_ctx *ctx, int which, uint64_t *out_xy, size_t max_points);
 
 /* ---- synthetic inputs generated on the device (bench / tests) -------------

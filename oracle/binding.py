@@ -192,6 +192,8 @@ def mul_by_generator_batch(scalars, out_form=0):
 def multiply_batch(pts, in_form, scalars, out_form=0, vartime=False):
     s = _u8(scalars).reshape(-1, 32)
     p = _u64(pts).reshape(len(s), 12 if in_form == 0 else 18)
+    if {in_form, out_form} >= {1, 2}:
+        raise ValueError("PROJECTIVE and JACOBIAN cannot be mixed")
     out, inf = _out_bufs(len(s), out_form)
     f = lib().ora_multiply_vartime_batch if vartime else lib().ora_multiply_batch
     f(p, in_form, s, out, inf, len(s), out_form)

@@ -1254,9 +1254,13 @@ void ora_fp6_invert_batch(const u64 *a, u64 *out, uint8_t *is_some, size_t n) {
     }
 }
 
-static void emit_point(proj r, u64 *out, uint8_t *out_inf, size_t i, int out_form) {
+/* in_form / out_form: 0 = affine, 1 = projective, 2 = Jacobian.  Which reference
+ * method a pair names: PROJECTIVE on either side -> ProjectivePoint::multiply*,
+ * otherwise JacobianPoint::multiply* (AffinePoint::multiply* delegates to it,
+ * src/curve/affine.rs:373-386). */
+static void emit_point(proj r, int jac, u64 *out, uint8_t *out_inf, size_t i, int out_form) {
     if (out_form == 0) {
-        affine a = affine_from_proj(r);
+        affine a = jac ? affine_from_jac(r) : affine_from_proj(r); /* src/curve/affine.rs:64-101 */
         affine_store(out + 12 * i, out_inf ? out_inf + i : NULL, a);
     } else {
         proj c = {fp6_canonical(r.x), fp6_canonical(r.y), fp6_canonical(r.z)};
@@ -1269,29 +1273,42 @@ static proj load_in_point(const u64 *pts, int in_form, size_t i) {
     if (in_form == 0) { /* affine x|y; (0, 1) is taken as the identity encoding, src/curve/affine.rs:224-230 */
         affine a = affine_load(pts + 12 * i, 0);
         a.inf = (uint8_t)(fp6_is_zero(a.x) && fp6_eq(a.y, FP6_ONE));
-        return proj_from_affine(a);
+        return proj_from_affine(a); /* JacobianPoint::from(&AffinePoint) has the same coordinates, src/curve/jacobian.rs:102-110 */
     }
     return proj_load(pts + 18 * i);
 }
 
 void ora_mul_by_generator_batch(const uint8_t *scalars, u64 *out, uint8_t *out_inf, size_t n, int out_form) {
     ora_init();
+    if (out_form == 2) ora_init_bpl();
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; i++) emit_point(basepoint_table_multiply(scalars + 32 * i), out, out_inf, i, out_form);
+    for (size_t i = 0; i < n; i++) {
+        if (out_form == 2) /* &BASEPOINT_LOOKUP * &Scalar, src/constants.rs:102-117 */
+            emit_point(basepoint_lookup_multiply(scalars + 32 * i), 1, out, out_inf, i, out_form);
+        else
+            emit_point(basepoint_table_multiply(scalars + 32 * i), 0, out, out_inf, i, out_form);
+    }
 }
 void ora_multiply_batch(const u64 *pts, int in_form, const uint8_t *scalars, u64 *out, uint8_t *out_inf, size_t n,
                         int out_form) {
     ora_init();
+    const int jac = !(in_form == 1 || out_form == 1);
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; i++)
-        emit_point(proj_multiply(load_in_point(pts, in_form, i), scalars + 32 * i), out, out_inf, i, out_form);
+    for (size_t i = 0; i < n; i++) {
+        proj p = load_in_point(pts, in_form, i);
+        emit_point(jac ? jac_multiply(p, scalars + 32 * i) : proj_multiply(p, scalars + 32 * i), jac, out, out_inf, i, out_form);
+    }
 }
 void ora_multiply_vartime_batch(const u64 *pts, int in_form, const uint8_t *scalars, u64 *out, uint8_t *out_inf, size_t n,
                                 int out_form) {
     ora_init();
+    const int jac = !(in_form == 1 || out_form == 1);
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; i++)
-        emit_point(proj_multiply_vartime(load_in_point(pts, in_form, i), scalars + 32 * i), out, out_inf, i, out_form);
+    for (size_t i = 0; i < n; i++) {
+        proj p = load_in_point(pts, in_form, i);
+        emit_point(jac ? jac_multiply_vartime(p, scalars + 32 * i) : proj_multiply_vartime(p, scalars + 32 * i), jac, out, out_inf,
+                   i, out_form);
+    }
 }
 
 static void batch_normalize_chunked(const u64 *p, size_t n, size_t chunk, u64 *xy, uint8_t *inf, int jac) {

@@ -112,8 +112,12 @@ void ora_jac_multiply_vartime(const uint64_t *p, const uint8_t *by32, uint64_t *
 
 /* ---- batch drivers used by tests and by bench.py's cpu_baseline leg.
  * Independent elements are split statically over OpenMP threads (the analogue
- * of a rayon par_iter over the reference's scalar API).  out_form: 0 = affine
- * (out_xy 12 limbs + out_inf), 1 = projective (18 limbs canonical). ---- */
+ * of a rayon par_iter over the reference's scalar API).  Forms: 0 = affine
+ * (12 limbs + inf flag), 1 = projective, 2 = Jacobian (18 limbs canonical).  A pair
+ * with PROJECTIVE on either side runs ProjectivePoint::multiply*, any other pair
+ * JacobianPoint::multiply* (what AffinePoint::multiply* delegates to);
+ * ora_mul_by_generator_batch runs BASEPOINT_TABLE for forms 0 / 1 and
+ * BASEPOINT_LOOKUP for form 2. ---- */
 int ora_num_threads(void);
 void ora_fp6_mul_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 void ora_fp6_square_batch(const uint64_t *a, uint64_t *out, size_t n);

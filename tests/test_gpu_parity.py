@@ -99,7 +99,7 @@ def test_fp6_device_functions(eng, ora):
 
 
 def _random_points(ora, seed, n, form):
-    """k_i * G as projective (scaled by a random lambda) or affine."""
+    """k_i * G as affine, projective or Jacobian (the latter two scaled by a random lambda)."""
     sc = synth.scalars(seed, n)
     xy, inf = ora.mul_by_generator_batch(sc, 0)
     if form == "affine":
@@ -107,8 +107,13 @@ def _random_points(ora, seed, n, form):
     lam = synth.fp6_elements(seed + 1000, n)
     out = np.zeros((n, 18), np.uint64)
     for i in range(n):
-        out[i, 0:6] = ora.fp6_binop("ora_fp6_mul", xy[i, 0:6], lam[i])
-        out[i, 6:12] = ora.fp6_binop("ora_fp6_mul", xy[i, 6:12], lam[i])
+        if form == "jac":  # (x l^2, y l^3, l), the construction of src/curve/jacobian.rs:1383-1387
+            l2 = ora.fp6_unop("ora_fp6_square", lam[i])
+            out[i, 0:6] = ora.fp6_binop("ora_fp6_mul", xy[i, 0:6], l2)
+            out[i, 6:12] = ora.fp6_binop("ora_fp6_mul", xy[i, 6:12], ora.fp6_binop("ora_fp6_mul", l2, lam[i]))
+        else:
+            out[i, 0:6] = ora.fp6_binop("ora_fp6_mul", xy[i, 0:6], lam[i])
+            out[i, 6:12] = ora.fp6_binop("ora_fp6_mul", xy[i, 6:12], lam[i])
         out[i, 12:18] = lam[i]
     return out
 
@@ -242,6 +247,9 @@ def test_tables_vs_oracle(eng, ora, kats):
     assert (sh[1] == ms[4]).all() and (sh[2] == ms[256]).all()
     assert list(bpt[0]) == kats["generator"]["x"] + kats["generator"]["y"]
     assert list(bpt[1]) == kats["two_g_affine"]["x"] + kats["two_g_affine"]["y"]  # 2G KAT, src/curve/projective.rs:1157-1178
+    bpl = eng.read_table(2)  # BASEPOINT_LOOKUP = [G .. 128 G], src/constants.rs:26-27
+    assert (bpl == ora.table("ora_basepoint_lookup", 128)).all()
+    assert (bpl[:8] == bpt[:8]).all()
 
 
 # --------------------------------------------------------- batch_normalize ----
@@ -328,6 +336,30 @@ def test_mul_by_generator_seeded_vs_oracle(eng, ora, n):
     assert (host(eng.synth_scalars(2, n)) == sc).all()
 
 
+def test_basepoint_lookup_jacobian(eng, ora):
+    """`&BASEPOINT_LOOKUP * &Scalar` (src/constants.rs:102-135): the reference's Jacobian
+    (X, Y, Z), edge scalars included (digit 31 wraps to -128 for a top byte of 0x7f + carry,
+    as the reference's `as i8` does), and BASEPOINT_LOOKUP * c == BASEPOINT_TABLE * c
+    (src/curve/jacobian.rs:1612-1626)."""
+    from cheetah_amd import AFFINE, JACOBIAN
+    n = 300
+    sc = synth.scalars(6, n)
+    edge = [0, 1, 2, 127, 128, 129, 255, 256, Q - 1, Q, (1 << 255) - 1, (0x7f << 248) | (0x80 << 240), (1 << 256) - 1]
+    for i, k in enumerate(edge):
+        sc[i] = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    S = dev(sc)
+    jac, jinf = eng.mul_by_generator_batch(S, JACOBIAN)
+    wjac, wjinf = ora.mul_by_generator_batch(sc, 2)
+    assert (host(jac) == wjac).all() and (host(jinf) == wjinf).all()
+    from cheetah_amd import JACOBIAN as J
+    xy, inf = eng.batch_normalize(jac, J)
+    can = np.array([int.from_bytes(bytes(s), "little") < Q for s in sc])
+    txy, tinf = eng.mul_by_generator_batch(dev(sc[can]), AFFINE)
+    assert (host(xy)[can] == host(txy)).all() and (host(inf)[can] == host(tinf)).all()
+    hj, hi = eng.mul_by_generator_batch(sc, JACOBIAN)  # host-pointer entry point takes any 32 bytes on this path
+    assert (hj == wjac).all() and (hi == wjinf).all()
+
+
 # ----------------------------------------------------------- variable base ----
 
 def test_multiply_golden(eng, model_vectors):
@@ -350,7 +382,7 @@ def test_multiply_vs_oracle_all_forms(eng, ora, n):
     """ct and vartime ladders; affine and projective inputs; affine output (L1) and
     the reference's projective representative (L2); multiply == multiply_vartime
     (src/curve/projective.rs:1339)."""
-    from cheetah_amd import AFFINE, PROJECTIVE
+    from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE, CheetahError
     sc = synth.scalars(3, n)
     aff = _random_points(ora, 81, n, "affine")
     prj = _random_points(ora, 81, n, "proj")
@@ -363,6 +395,9 @@ def test_multiply_vs_oracle_all_forms(eng, ora, n):
         prj[20, 12:18] = 0                      # projective identity
         sc[21] = 255                            # non-canonical 2^256 - 1: needs LookupTable<16>'s entry 16
     S = dev(sc)
+    jac = _random_points(ora, 81, n, "jac")
+    if n >= 64:
+        jac[20, 12:18] = 0                      # Jacobian identity
     for vartime in (False, True):
         f = eng.multiply_vartime_batch if vartime else eng.multiply_batch
         for in_form, pts in ((AFFINE, aff), (PROJECTIVE, prj)):
@@ -373,6 +408,17 @@ def test_multiply_vs_oracle_all_forms(eng, ora, n):
             wpr, wpinf = ora.multiply_batch(pts, in_form, sc, 1, vartime=vartime)
             pr, pinf = f(Pd, S, in_form, PROJECTIVE)
             assert (host(pr) == wpr).all() and (host(pinf) == wpinf).all(), (vartime, in_form)
+        # JacobianPoint::multiply* (src/curve/jacobian.rs:599-649): the reference's own Jacobian (X, Y, Z)
+        for in_form, pts in ((AFFINE, aff), (JACOBIAN, jac)):
+            Pd = dev(pts)
+            wj, wjinf = ora.multiply_batch(pts, in_form, sc, 2, vartime=vartime)
+            j, jinf = f(Pd, S, in_form, JACOBIAN)
+            assert (host(j) == wj).all() and (host(jinf) == wjinf).all(), (vartime, in_form)
+        wxy, winf = ora.multiply_batch(jac, JACOBIAN, sc, 0, vartime=vartime)
+        xy, inf = f(dev(jac), S, JACOBIAN, AFFINE)
+        assert (host(xy) == wxy).all() and (host(inf) == winf).all(), vartime
+        with pytest.raises(CheetahError):
+            f(dev(prj), S, PROJECTIVE, JACOBIAN)
     # cross-path: ct == vartime on canonical scalars
     can = np.array([int.from_bytes(bytes(s), "little") < 2**255 for s in sc])
     a1, i1 = eng.multiply_batch(dev(aff), S, AFFINE, AFFINE)
