@@ -5,7 +5,8 @@ multiplications per second, plus Fp6 multiplications per second.
     python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE config 5): 2^26 seeded (P_i, k_i) pairs, out[i] = k_i * P_i by
-ProjectivePoint::multiply (src/curve/projective.rs:614-625), affine results.  The
+AffinePoint::multiply (src/curve/affine.rs:373-375 -> JacobianPoint::multiply,
+src/curve/jacobian.rs:599-611), affine results.  The
 2^26 pairs are sharded over the N ranks (strong scaling: the total is fixed) and
 the affine results are all-gathered over RCCL so that every rank holds all of
 them.  Inputs are synthetic, generated on the device (points r_i * G, seeded
@@ -25,8 +26,14 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# reference-algorithm work per unit (SURVEY.md 8d / BASELINE.md 2)
-MAD32_PER_CT_MULT = 348468      # 87 117 Fp mul x 4 v_mad_u64_u32
+# reference-algorithm work per unit (SURVEY.md 8d / BASELINE.md 2; derivation in DESIGN.md 5).
+# Affine in / affine out is AffinePoint::multiply, which runs JacobianPoint::multiply
+# (src/curve/affine.rs:373-375, src/curve/jacobian.rs:599-611):
+#   LookupTable<16>::from(&JacobianPoint): normalise 300 + 15 complete adds x 300 + batch_normalize(16) 2 103 = 6 903
+#   64 windows x (4 x 180 + 297) = 65 088;  - 2^256 S correction 297;  final normalisation 300
+FPMUL_PER_CT_MULT = 72588
+MAD32_PER_CT_MULT = 4 * FPMUL_PER_CT_MULT   # 1 Fp mul = 4 v_mad_u64_u32 on 32-bit limbs
+MAD32_PER_CT_MULT_PROJECTIVE = 348468       # ProjectivePoint::multiply, for comparison only
 FP6_MUL_BYTES = 144             # 2 x 48 in + 48 out
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
 
@@ -60,7 +67,7 @@ def cpu_baseline(n_sample, seed=5):
         ora.multiply_batch(pts, 0, k, 0)
         best = min(best, time.perf_counter() - t0)
     return {"value": n_sample / best, "unit": "scalar_mults/s", "cores": int(cores), "kind": "port",
-            "sample": "2^%d of the 2^26 (P,k) pairs, oracle ora_multiply_batch (C restatement of ProjectivePoint::multiply, "
+            "sample": "2^%d of the 2^26 (P,k) pairs, oracle ora_multiply_batch (C restatement of AffinePoint::multiply, "
                       "OpenMP static split over %d threads), best of 2" % (int(np.log2(n_sample)), cores)}
 
 
@@ -173,7 +180,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "2^%d variable-base constant-time scalar mults (ProjectivePoint::multiply), affine in/out, "
+            "config": {"workload": "2^%d variable-base constant-time scalar mults (AffinePoint::multiply = JacobianPoint::multiply ladder), affine in/out, "
                                    "sharded over %d GPU(s), RCCL all-gather of results (BASELINE config 5)" % (args.log2n, world),
                        "n": n, "per_gpu": n // world, "allgather_chunks": chunks, "parallelism": "shard%d" % world},
             "fp6_muls_per_s": fp6_rate,
@@ -183,8 +190,10 @@ def main():
                          "unit": "Tmad32/s", "frac": achieved / mad_peak, "traffic": None,
                          "ms_per_launch": ms_launch, "units_per_launch": units_per_launch,
                          "mad32_per_unit": MAD32_PER_CT_MULT,
-                         "note": "achieved = reference-algorithm mad32 count (87117 Fp mul x 4) x units / HIP-event launch time; "
-                                 "peak = v_mad_u64_u32 issue rate measured live on this device"},
+                         "frac_if_credited_as_ProjectivePoint_multiply": achieved * MAD32_PER_CT_MULT_PROJECTIVE / MAD32_PER_CT_MULT / mad_peak,
+                         "note": "achieved = reference-algorithm mad32 count of AffinePoint::multiply (72588 Fp mul x 4) x units / "
+                                 "HIP-event launch time; peak = v_mad_u64_u32 issue rate measured live on this device; the kernel "
+                                 "is VALU-issue bound (profiles/, DESIGN.md 5): carries and reductions issue at the same rate as the mads"},
             "roofline_fp6_mul": {"bound": "hbm", "kernel": "k_fp6_elementwise<mul>", "achieved": fp6_gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": fp6_gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": fp6_ms,
                                  "units_per_launch": nf, "bytes_per_unit": FP6_MUL_BYTES},

@@ -45,6 +45,7 @@ static int32_t fail(cheetah_ctx* ctx, int32_t code, const char* msg) {
 }
 
 static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Generator (src/curve/affine.rs:255-275) and shift point (src/constants.rs:43-61).
 static const u64 GENERATOR_XY[12] = {
@@ -179,7 +180,7 @@ static int32_t fp6_elementwise_dev(cheetah_ctx* ctx, const u64* a, const u64* b,
     CHECK_CTX(ctx);
     if (n == 0) return CHEETAH_OK;
     if (!a || !out || (OP == EW_MUL && !b)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned8(a) || !aligned8(out) || (b && !aligned8(b))) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    if (!aligned16(a) || !aligned16(out) || (b && !aligned16(b))) return fail(ctx, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
     size_t tiles = (n + BLOCK - 1) / BLOCK;
     size_t cap = (size_t)ctx->num_cus * 8;
     int grid = (int)(tiles < cap ? tiles : cap);

@@ -137,62 +137,48 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
 
 // ---------------------------------------------------------------------------
 // Elementwise Fp6 kernels (config 1): HBM-bound, 144 B per multiplication.
-// AoS elements are 48 B, so a lane's own element is not a coalesced access:
-// each workgroup moves its 256-element tile (12 KiB per operand) between HBM
-// and LDS with fully coalesced 8-byte accesses and lanes pick their element
-// out of LDS.
+// An element is 48 contiguous bytes = three 16-byte words; lane i of a wave reads
+// words 3i, 3i+1, 3i+2 of the wave's 3 KiB span with three global_load_dwordx4.
+// Every 128-byte line of the span is touched by all three instructions, which
+// issue back to back, so the line is fetched from HBM once and served from the
+// CU's L1 after that; no LDS staging and no barriers, which leaves the waves
+// free to overlap one element's loads with another's arithmetic.
 enum { EW_MUL = 0, EW_SQUARE = 1, EW_INVERT = 2 };
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+CH_DEV Fp6 load_fp6_vec(const u64* p) {  // p is 16-byte aligned
+    const u64x2* q = reinterpret_cast<const u64x2*>(p);
+    u64x2 v0 = q[0], v1 = q[1], v2 = q[2];
+    Fp6 r;
+    r.c[0] = v0.x; r.c[1] = v0.y; r.c[2] = v1.x; r.c[3] = v1.y; r.c[4] = v2.x; r.c[5] = v2.y;
+    return r;
+}
+CH_DEV void store_fp6_vec_canonical(u64* p, const Fp6& a) {
+    u64x2* q = reinterpret_cast<u64x2*>(p);
+    u64x2 v0, v1, v2;
+    v0.x = fp_canonical(a.c[0]); v0.y = fp_canonical(a.c[1]);
+    v1.x = fp_canonical(a.c[2]); v1.y = fp_canonical(a.c[3]);
+    v2.x = fp_canonical(a.c[4]); v2.y = fp_canonical(a.c[5]);
+    q[0] = v0; q[1] = v1; q[2] = v2;
+}
 
 template <int OP>
 __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict__ a, const u64* __restrict__ b,
                                                            u64* __restrict__ out, u8* __restrict__ is_some, size_t n) {
-    __shared__ u64 sa[BLOCK * 6];
-    __shared__ u64 sb[OP == EW_MUL ? BLOCK * 6 : 1];
-    const int t = threadIdx.x;
-    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const size_t e0 = tile * BLOCK;
-        const size_t cnt = (n - e0 < (size_t)BLOCK) ? n - e0 : (size_t)BLOCK;
-        const size_t words = cnt * 6;
-        const u64* ga = a + e0 * 6;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            size_t w = (size_t)t + (size_t)k * BLOCK;
-            if (w < words) sa[w] = ga[w];
-        }
-        if (OP == EW_MUL) {
-            const u64* gb = b + e0 * 6;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                size_t w = (size_t)t + (size_t)k * BLOCK;
-                if (w < words) sb[w] = gb[w];
-            }
-        }
-        __syncthreads();
-        Fp6 r = fp6_zero();
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const Fp6 x = load_fp6_vec(a + 6 * i);
+        Fp6 r;
         bool some = true;
-        if ((size_t)t < cnt) {
-            Fp6 x = load_fp6(sa + 6 * t);
-            if (OP == EW_MUL)
-                r = fp6_mul(x, load_fp6(sb + 6 * t));
-            else if (OP == EW_SQUARE)
-                r = fp6_square(x);
-            else
-                r = fp6_invert(x, &some);
-        }
-        __syncthreads();
-        if ((size_t)t < cnt) {
-            store_fp6_canonical(sa + 6 * t, r);
-            if (OP == EW_INVERT && is_some) is_some[e0 + t] = some ? 1 : 0;
-        }
-        __syncthreads();
-        u64* go = out + e0 * 6;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            size_t w = (size_t)t + (size_t)k * BLOCK;
-            if (w < words) go[w] = sa[w];
-        }
-        __syncthreads();
+        if (OP == EW_MUL)
+            r = fp6_mul(x, load_fp6_vec(b + 6 * i));
+        else if (OP == EW_SQUARE)
+            r = fp6_square(x);
+        else
+            r = fp6_invert(x, &some);
+        store_fp6_vec_canonical(out + 6 * i, r);
+        if (OP == EW_INVERT && is_some) is_some[i] = some ? 1 : 0;
     }
 }
 

@@ -21,7 +21,7 @@
  *    aborts or throws across the boundary; cheetah_last_error() has the text.
  *  - a context belongs to ONE device and one host thread at a time; calls are
  *    issued on the context's stream.  `_dev` entry points take DEVICE pointers
- *    (8-byte aligned) and are asynchronous on that stream; the others take HOST
+ *    (8-byte aligned; Fp6 arrays 16-byte aligned) and are asynchronous on that stream; the others take HOST
  *    pointers, copy, run the same kernels and return after the results are back.
  *  - the caller owns all buffers; the library keeps no pointer after return.
  */
