@@ -206,10 +206,10 @@ static int32_t batch_normalize_dev(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8
     CHECK_CTX(ctx);
     if (n == 0) return CHEETAH_OK;
     if (!xyz || !xy || !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned8(xyz) || !aligned8(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    if (!aligned16(xyz) || !aligned16(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "point arrays must be 16-byte aligned");
     constexpr int CHUNK = 8;
     size_t nchunks = (n + CHUNK - 1) / CHUNK;
-    int grid = lane_grid(ctx, nchunks, 8);
+    int grid = lane_grid(ctx, nchunks, 2);
     hipLaunchKernelGGL((k_batch_normalize<JAC, CHUNK>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;

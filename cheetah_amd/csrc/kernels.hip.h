@@ -186,23 +186,29 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
 // batch_normalize (config 4).  The reference runs ONE sequential Montgomery
 // chain over the whole slice (src/curve/projective.rs:897-930,
 // src/curve/jacobian.rs:886-920).  Here every lane runs the same trick over its
-// own CHUNK consecutive points: prefix products of the non-zero z's, one Fp6
-// inversion per lane, then the backward pass.  Identities (z = 0) are skipped in
-// the chain and come out as (0, 1, inf = 1) exactly as in the reference.
-// Exact field arithmetic makes the re-association invisible in the results.
+// own CHUNK points: prefix products of the non-zero z's, one Fp6 inversion per
+// lane, then the backward pass.  Identities (z = 0) are skipped in the chain and
+// come out as (0, 1, inf = 1) exactly as in the reference.  Exact field
+// arithmetic makes the re-association invisible in the results.
+// A lane's chunk is strided: lane t of a workgroup owns points
+// tile + t, tile + BLOCK + t, ..., so at every step the workgroup touches BLOCK
+// consecutive 144-byte records with 16-byte accesses -- each 128-byte line is
+// fetched from HBM once -- instead of one record per 1 152 bytes.
 template <int JAC, int CHUNK>
-__global__ void __launch_bounds__(BLOCK) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
-                                                           u8* __restrict__ inf, size_t n) {
-    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
-    for (size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * BLOCK) {
-        const size_t e0 = c * CHUNK;
-        Fp6 prefix[CHUNK];  // prefix[j] = product of non-zero z's before point j
+__global__ void __launch_bounds__(BLOCK, 2) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
+                                                              u8* __restrict__ inf, size_t n) {
+    const size_t tile_pts = (size_t)BLOCK * CHUNK;
+    const size_t ntiles = (n + tile_pts - 1) / tile_pts;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t e0 = tile * tile_pts + threadIdx.x;
+        Fp6 prefix[CHUNK];  // prefix[j] = product of the lane's non-zero z's before its point j
         Fp6 acc = fp6_one();
 #pragma unroll
         for (int j = 0; j < CHUNK; j++) {
+            const size_t e = e0 + (size_t)j * BLOCK;
             prefix[j] = acc;
-            if (e0 + j < n) {
-                Fp6 z = load_fp6(xyz + 18 * (e0 + j) + 12);
+            if (e < n) {
+                Fp6 z = load_fp6_vec(xyz + 18 * e + 12);
                 Fp6 m = fp6_mul(acc, z);
                 acc = fp6_select(m, acc, fp6_is_zero(z));
             }
@@ -211,9 +217,10 @@ __global__ void __launch_bounds__(BLOCK) k_batch_normalize(const u64* __restrict
         acc = fp6_invert(acc, &some);
 #pragma unroll
         for (int j = CHUNK - 1; j >= 0; j--) {
-            if (e0 + j < n) {
-                const u64* p = xyz + 18 * (e0 + j);
-                Fp6 z = load_fp6(p + 12);
+            const size_t e = e0 + (size_t)j * BLOCK;
+            if (e < n) {
+                const u64* p = xyz + 18 * e;
+                Fp6 z = load_fp6_vec(p + 12);
                 const bool skip = fp6_is_zero(z);
                 Fp6 zi = fp6_mul(prefix[j], acc);  // 1 / z_j
                 Fp6 m = fp6_mul(acc, z);
@@ -221,15 +228,17 @@ __global__ void __launch_bounds__(BLOCK) k_batch_normalize(const u64* __restrict
                 Affine o;
                 if (JAC) {
                     Fp6 zi2 = fp6_square(zi);
-                    o.x = fp6_mul(load_fp6(p), zi2);
-                    o.y = fp6_mul(fp6_mul(load_fp6(p + 6), zi2), zi);
+                    o.x = fp6_mul(load_fp6_vec(p), zi2);
+                    o.y = fp6_mul(fp6_mul(load_fp6_vec(p + 6), zi2), zi);
                 } else {
-                    o.x = fp6_mul(load_fp6(p), zi);
-                    o.y = fp6_mul(load_fp6(p + 6), zi);
+                    o.x = fp6_mul(load_fp6_vec(p), zi);
+                    o.y = fp6_mul(load_fp6_vec(p + 6), zi);
                 }
                 o.inf = false;
                 if (skip) o = affine_identity();
-                store_affine(xy, inf, e0 + j, o);
+                store_fp6_vec_canonical(xy + 12 * e, o.x);
+                store_fp6_vec_canonical(xy + 12 * e + 6, o.y);
+                inf[e] = o.inf ? 1 : 0;
             }
         }
     }
