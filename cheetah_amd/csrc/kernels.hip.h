@@ -566,7 +566,6 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __
 // src/curve/jacobian.rs:619-649, src/curve/affine.rs:384-386), with their
 // quirk Q1: the "skip unset digits" loop never moves i off 255, so there are
 // always 256 doublings and the correction is MINUS_SHIFT_POINT_ARRAY[256].
-// Lanes add only where their own NAF digit is non-zero (divergent by nature).
 template <class ACC, int IN_FORM, int OUT_FORM>
 __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
@@ -592,16 +591,36 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
         const Proj p = load_input_point<IN_FORM>(pts, ii);
         const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
         ACC acc = Ladder<ACC>::from_affine(shift);
-        for (int j = 255; j >= 0; j--) {
-            acc = Ladder<ACC>::dbl(acc);
-            const int d = s_naf[j * BLOCK + t];
-            if (d != 0) {
-                const int e = (d < 0 ? -d : d) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
-                Affine q;
-                q.x = sc_load(s_tab, e, 0, t, 12);
-                q.y = sc_load(s_tab, e, 6, t, 12);
-                q.inf = (ident >> e) & 1;
-                acc = Ladder<ACC>::add(acc, affine_cond_neg(q, d < 0));
+        // Every lane runs ITS OWN reference sequence (256 doublings, an addition after
+        // each non-zero digit), so the representative it ends with is the reference's.
+        // What is scheduled is only WHEN the wave executes which step: a lane that
+        // reaches a non-zero digit parks until the wave's next addition phase, and the
+        // wave adds once 3/4 of it is parked (or nobody can double).  Lanes drift apart
+        // by a few positions; on seeded scalars this costs ~349 doubling + ~55 addition
+        // phases per wave instead of 256 + 256 for a lock-step loop.
+        int pos = 255;       // next digit position of this lane
+        int pd = 0;          // parked digit
+        for (;;) {
+            const bool can = pd == 0 && pos >= 0;
+            const u64 m_can = __builtin_amdgcn_ballot_w64(can);
+            const u64 m_pend = __builtin_amdgcn_ballot_w64(pd != 0);
+            if (m_can == 0 && m_pend == 0) break;
+            if (m_pend != 0 && (__builtin_popcountll(m_pend) >= 48 || m_can == 0)) {
+                if (pd != 0) {
+                    const int e = (pd < 0 ? -pd : pd) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
+                    Affine q;
+                    q.x = sc_load(s_tab, e, 0, t, 12);
+                    q.y = sc_load(s_tab, e, 6, t, 12);
+                    q.inf = (ident >> e) & 1;
+                    acc = Ladder<ACC>::add(acc, affine_cond_neg(q, pd < 0));
+                    pd = 0;
+                }
+                continue;
+            }
+            if (can) {
+                acc = Ladder<ACC>::dbl(acc);
+                pd = s_naf[pos * BLOCK + t];
+                pos--;
             }
         }
         acc = Ladder<ACC>::add(acc, mshift);
