@@ -156,6 +156,8 @@ static int lane_grid(const cheetah_ctx* ctx, size_t n_lanes_needed, int blocks_p
     return g ? (int)g : 1;
 }
 
+constexpr int ROUNDS_PER_LAUNCH = 2;
+
 static int32_t ensure_scratch(cheetah_ctx* ctx, size_t words) {
     if (ctx->scratch_words >= words) return CHEETAH_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -244,12 +246,20 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
     if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     int grid = lane_grid(ctx, n, 2);
-    if (out_form == CHEETAH_AFFINE)
-        hipLaunchKernelGGL((k_mul_by_generator<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
-    else if (out_form == CHEETAH_PROJECTIVE)
-        hipLaunchKernelGGL((k_mul_by_generator<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
-    else
-        hipLaunchKernelGGL((k_mul_by_generator_lookup<2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, scalars32, out, inf, n);
+    const size_t out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH * 4;  // bounded launches, as in multiply_dev
+    for (size_t off = 0; off < n; off += per_launch) {
+        const size_t cnt = n - off < per_launch ? n - off : per_launch;
+        const u8* sc_o = scalars32 + off * 32;
+        u64* out_o = out + off * out_w;
+        u8* inf_o = inf ? inf + off : nullptr;
+        if (out_form == CHEETAH_AFFINE)
+            hipLaunchKernelGGL((k_mul_by_generator<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, sc_o, out_o, inf_o, cnt);
+        else if (out_form == CHEETAH_PROJECTIVE)
+            hipLaunchKernelGGL((k_mul_by_generator<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, sc_o, out_o, inf_o, cnt);
+        else
+            hipLaunchKernelGGL((k_mul_by_generator_lookup<2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, sc_o, out_o, inf_o, cnt);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }
@@ -264,8 +274,20 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     int grid = lane_grid(ctx, n, 2);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
+    // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (~25 ms of
+    // work).  The workgroups are persistent within a launch and fill every CU, so a kernel
+    // on another stream (the RCCL all-gather of the previous chunk) can only get CU slots
+    // at a launch boundary: bounding the launch bounds how long it waits.
+    const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;
+    for (size_t off = 0; off < n; off += per_launch) {
+        const size_t cnt = n - off < per_launch ? n - off : per_launch;
+        const u64* pts_o = pts + off * in_w;
+        const u8* sc_o = scalars32 + off * 32;
+        u64* out_o = out + off * out_w;
+        u8* inf_o = inf ? inf + off : nullptr;
 #define LAUNCH(KERN, A, I, O) \
-    hipLaunchKernelGGL((KERN<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts, scalars32, out, inf, n, ctx->scratch)
+    hipLaunchKernelGGL((KERN<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o, out_o, inf_o, cnt, ctx->scratch)
 #define DISPATCH(KERN)                                         \
     switch (in_form * 3 + out_form) {                          \
         case 0: LAUNCH(KERN, MJac, 0, 0); break; /* A -> A */ \
@@ -276,10 +298,11 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         case 6: LAUNCH(KERN, MJac, 2, 0); break; /* J -> A */ \
         default: LAUNCH(KERN, MJac, 2, 2); break; /* J -> J */ \
     }
-    if (VARTIME) {
-        DISPATCH(k_multiply_vartime)
-    } else {
-        DISPATCH(k_multiply_ct)
+        if (VARTIME) {
+            DISPATCH(k_multiply_vartime)
+        } else {
+            DISPATCH(k_multiply_ct)
+        }
     }
 #undef DISPATCH
 #undef LAUNCH
