@@ -40,6 +40,16 @@ SIGNATURES = {
     "cheetah_multiply_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
     "cheetah_multiply_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
     "cheetah_multiply_vartime_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_many_batch": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_many_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_double_with_basepoint_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_many_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_many_vartime_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_double_with_basepoint_vartime_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_is_torsion_free_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_clear_cofactor_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz, _i]),
+    "cheetah_is_torsion_free_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_clear_cofactor_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz, _i]),
     "cheetah_read_table": (C.c_int32, [_vp, _i, _vp, _sz]),
     "cheetah_synth_fp6_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),
     "cheetah_synth_scalars_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),

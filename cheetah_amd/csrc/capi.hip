@@ -20,10 +20,11 @@ struct cheetah_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     DeviceTables* tables = nullptr;
+    u8* fixed_scalars = nullptr;  // q | cofactor, 64 bytes (is_torsion_free / clear_cofactor)
     u64* scratch = nullptr;
     size_t scratch_words = 0;
     int num_cus = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     std::string err;
 };
 
@@ -56,6 +57,12 @@ static const u64 SHIFT_XY[12] = {
     0xab95fb0d188ff2b1ull, 0xf38263a8c954493eull, 0x1bc968d6739028b7ull, 0x4f67684fe6b27d1full,
     0x6504f8bbba9077b4ull, 0x860838116d76e545ull, 0x56988918d5b02cf3ull, 0xc9fe3ef9d7652c54ull,
     0x4923e90c4d6f4538ull, 0xc747ac3f82369f27ull, 0x6e74c106972c71f5ull, 0xcf190938f1c64bb5ull};
+
+// q (src/curve/projective.rs:886-889) and the cofactor (:875-878), little-endian, in device memory of the context.
+static const u8 FQ_MODULUS_BYTES[32] = {207, 172, 212, 174, 62, 98, 67, 212, 34, 119, 21, 48, 35, 167, 122, 50,
+                                        181, 55, 10, 153, 15, 191, 63, 86, 208, 34, 63, 59, 155, 89, 242, 122};
+static const u8 COFACTOR_BYTES[32] = {74, 78, 48, 84, 93, 63, 188, 73, 0, 97, 239, 113, 224, 72, 11, 21, 2};
+
 
 extern "C" const char* cheetah_version(void) { return "cheetah-hip 0.1 (gfx950)"; }
 
@@ -100,7 +107,11 @@ extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
     ctx->stream = ctx->own_stream;
     CREATE_TRY(hipEventCreate(&ctx->ev0));
     CREATE_TRY(hipEventCreate(&ctx->ev1));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(&ctx->tables, sizeof(DeviceTables)));
+    CREATE_TRY(hipMalloc(&ctx->fixed_scalars, 64));
+    CREATE_TRY(hipMemcpyAsync(ctx->fixed_scalars, FQ_MODULUS_BYTES, 32, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_TRY(hipMemcpyAsync(ctx->fixed_scalars + 32, COFACTOR_BYTES, 32, hipMemcpyHostToDevice, ctx->stream));
     u64* seeds = nullptr;
     CREATE_TRY(hipMalloc(&seeds, 24 * sizeof(u64)));
     CREATE_TRY(hipMemcpyAsync(seeds, GENERATOR_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
@@ -119,24 +130,36 @@ extern "C" int32_t cheetah_ctx_destroy(cheetah_ctx* ctx) {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->tables) (void)hipFree(ctx->tables);
+    if (ctx->fixed_scalars) (void)hipFree(ctx->fixed_scalars);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return CHEETAH_OK;
 }
 
+// The context's kernels share its scratch arena, so its work must stay ordered when the
+// stream changes: the new stream waits (on the device, no host sync) for what the
+// context has already enqueued on the old one.
+static int32_t switch_stream(cheetah_ctx* ctx, hipStream_t next) {
+    if (next == ctx->stream) return CHEETAH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(next, ctx->ev_order, 0));
+    ctx->stream = next;
+    return CHEETAH_OK;
+}
+
 extern "C" int32_t cheetah_ctx_set_stream(cheetah_ctx* ctx, void* hip_stream) {
     if (!ctx) return CHEETAH_ERR_INVALID;
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
-    return CHEETAH_OK;
+    return switch_stream(ctx, static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int32_t cheetah_ctx_use_own_stream(cheetah_ctx* ctx) {
     if (!ctx) return CHEETAH_ERR_INVALID;
-    ctx->stream = ctx->own_stream;
-    return CHEETAH_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 extern "C" int32_t cheetah_ctx_synchronize(cheetah_ctx* ctx) {
@@ -160,7 +183,7 @@ constexpr int ROUNDS_PER_LAUNCH = 2;
 
 static int32_t ensure_scratch(cheetah_ctx* ctx, size_t words) {
     if (ctx->scratch_words >= words) return CHEETAH_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipDeviceSynchronize());  // nothing may still be using the old arena
     if (ctx->scratch) HIP_TRY(ctx, hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_words = 0;
@@ -286,8 +309,15 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         const u8* sc_o = scalars32 + off * 32;
         u64* out_o = out + off * out_w;
         u8* inf_o = inf ? inf + off : nullptr;
-#define LAUNCH(KERN, A, I, O) \
-    hipLaunchKernelGGL((KERN<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o, out_o, inf_o, cnt, ctx->scratch)
+#define LAUNCH(KERN, A, I, O)                                                                                                   \
+    do {                                                                                                                       \
+        if (VARTIME)                                                                                                           \
+            hipLaunchKernelGGL((k_multiply_vartime<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o, \
+                               out_o, inf_o, cnt, ctx->scratch, 0);                                                            \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((k_multiply_ct<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o,      \
+                               out_o, inf_o, cnt, ctx->scratch);                                                               \
+    } while (0)
 #define DISPATCH(KERN)                                         \
     switch (in_form * 3 + out_form) {                          \
         case 0: LAUNCH(KERN, MJac, 0, 0); break; /* A -> A */ \
@@ -298,11 +328,7 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         case 6: LAUNCH(KERN, MJac, 2, 0); break; /* J -> A */ \
         default: LAUNCH(KERN, MJac, 2, 2); break; /* J -> J */ \
     }
-        if (VARTIME) {
-            DISPATCH(k_multiply_vartime)
-        } else {
-            DISPATCH(k_multiply_ct)
-        }
+        DISPATCH(_)
     }
 #undef DISPATCH
 #undef LAUNCH
@@ -458,6 +484,197 @@ extern "C" int32_t cheetah_multiply_vartime_batch(cheetah_ctx* ctx, const uint64
     return multiply_host<true>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
 }
 
+
+// --------------------------------------------- multi-scalar ladders, checks -----
+
+template <bool VARTIME>
+static int32_t multiply_many_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
+                                 u64* out, u8* inf, size_t n_groups, int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (m < 1 || m > CHEETAH_MAX_MANY) return fail(ctx, CHEETAH_ERR_INVALID, "m must be in [1, CHEETAH_MAX_MANY]");
+    if (n_groups == 0) return CHEETAH_OK;
+    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    const int ns = m + (with_basepoint ? 1 : 0);
+    int grid = lane_grid(ctx, n_groups, 2);
+    const size_t wpb = ManyScratch::words(m, ns);
+    if (int32_t rc = ensure_scratch(ctx, (size_t)grid * wpb)) return rc;
+    const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    size_t rounds = ROUNDS_PER_LAUNCH / (size_t)m;
+    if (rounds == 0) rounds = 1;
+    const size_t per_launch = (size_t)grid * BLOCK * rounds;
+    for (size_t off = 0; off < n_groups; off += per_launch) {
+        const size_t cnt = n_groups - off < per_launch ? n_groups - off : per_launch;
+        const u64* pts_o = pts + off * m * in_w;
+        const u8* sc_o = scalars32 + off * ns * 32;
+        u64* out_o = out + off * out_w;
+        u8* inf_o = inf ? inf + off : nullptr;
+#define LAUNCH(A, I, O)                                                                                                           \
+    do {                                                                                                                          \
+        if (VARTIME)                                                                                                              \
+            hipLaunchKernelGGL((k_multiply_many_vartime<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,    \
+                               sc_o, out_o, inf_o, cnt, m, with_basepoint, ctx->scratch, wpb);                                    \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((k_multiply_many_ct<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o,   \
+                               out_o, inf_o, cnt, m, ctx->scratch, wpb);                                                          \
+    } while (0)
+        switch (in_form * 3 + out_form) {
+            case 0: LAUNCH(MJac, 0, 0); break;
+            case 1: LAUNCH(Proj, 0, 1); break;
+            case 2: LAUNCH(MJac, 0, 2); break;
+            case 3: LAUNCH(Proj, 1, 0); break;
+            case 4: LAUNCH(Proj, 1, 1); break;
+            case 6: LAUNCH(MJac, 2, 0); break;
+            default: LAUNCH(MJac, 2, 2); break;
+        }
+#undef LAUNCH
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_multiply_many_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, int m,
+                                                   uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
+    return multiply_many_dev<false>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+}
+extern "C" int32_t cheetah_multiply_many_vartime_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
+                                                           const uint8_t* scalars32, int m, uint64_t* out, uint8_t* inf,
+                                                           size_t n_groups, int out_form) {
+    return multiply_many_dev<true>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+}
+extern "C" int32_t cheetah_multiply_double_with_basepoint_vartime_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
+                                                                            const uint8_t* scalars64, uint64_t* out, uint8_t* inf,
+                                                                            size_t n, int out_form) {
+    return multiply_many_dev<true>(ctx, pts, in_form, scalars64, 1, 1, out, inf, n, out_form);
+}
+
+// One fixed scalar for the whole batch through the vartime ladder (every lane has the
+// same NAF, so the wave never diverges).  out_form 3 = identity flag only.
+static int32_t fixed_scalar_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* dev_scalar, u64* out, u8* inf, size_t n,
+                                int out_form) {
+    int grid = lane_grid(ctx, n, 2);
+    if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
+    const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;
+    const bool proj = in_form == CHEETAH_PROJECTIVE || out_form == CHEETAH_PROJECTIVE;
+    for (size_t off = 0; off < n; off += per_launch) {
+        const size_t cnt = n - off < per_launch ? n - off : per_launch;
+        const u64* pts_o = pts + off * in_w;
+        u64* out_o = out ? out + off * out_w : nullptr;
+        u8* inf_o = inf ? inf + off : nullptr;
+#define LAUNCH(A, I, O) \
+    hipLaunchKernelGGL((k_multiply_vartime<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, dev_scalar, out_o, inf_o, cnt, ctx->scratch, 1)
+        if (out_form == 3) {  // flag only
+            if (in_form == CHEETAH_PROJECTIVE) LAUNCH(Proj, 1, 3);
+            else if (in_form == CHEETAH_JACOBIAN) LAUNCH(MJac, 2, 3);
+            else LAUNCH(MJac, 0, 3);
+        } else if (proj) {
+            if (in_form == CHEETAH_AFFINE) LAUNCH(Proj, 0, 1);
+            else if (out_form == CHEETAH_AFFINE) LAUNCH(Proj, 1, 0);
+            else LAUNCH(Proj, 1, 1);
+        } else {
+            if (in_form == CHEETAH_AFFINE && out_form == CHEETAH_AFFINE) LAUNCH(MJac, 0, 0);
+            else if (in_form == CHEETAH_AFFINE) LAUNCH(MJac, 0, 2);
+            else if (out_form == CHEETAH_AFFINE) LAUNCH(MJac, 2, 0);
+            else LAUNCH(MJac, 2, 2);
+        }
+#undef LAUNCH
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_is_torsion_free_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, CHEETAH_AFFINE)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!pts || !flags || !aligned8(pts)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
+    return fixed_scalar_dev(ctx, pts, in_form, ctx->fixed_scalars, nullptr, flags, n, 3);
+}
+extern "C" int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint64_t* out, uint8_t* inf,
+                                                    size_t n, int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!pts || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned8(pts) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    return fixed_scalar_dev(ctx, pts, in_form, ctx->fixed_scalars + 32, out, inf, n, out_form);
+}
+
+// host-pointer forms
+template <bool VARTIME>
+static int32_t multiply_many_host(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
+                                  u64* out, u8* inf, size_t n_groups, int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (m < 1 || m > CHEETAH_MAX_MANY) return fail(ctx, CHEETAH_ERR_INVALID, "m must be in [1, CHEETAH_MAX_MANY]");
+    if (n_groups == 0) return CHEETAH_OK;
+    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144, wo = out_form == CHEETAH_AFFINE ? 96 : 144;
+    const size_t ns = (size_t)m + (with_basepoint ? 1 : 0);
+    DevBuf dp, dsc, dout, dinf;
+    HIP_TRY(ctx, dp.alloc(n_groups * m * wi));
+    HIP_TRY(ctx, dsc.alloc(n_groups * ns * 32));
+    HIP_TRY(ctx, dout.alloc(n_groups * wo));
+    HIP_TRY(ctx, dinf.alloc(n_groups));
+    H2D(ctx, dp.p, pts, n_groups * m * wi);
+    H2D(ctx, dsc.p, scalars32, n_groups * ns * 32);
+    if (int32_t rc = multiply_many_dev<VARTIME>(ctx, dp.as<u64>(), in_form, dsc.as<u8>(), m, with_basepoint, dout.as<u64>(),
+                                                dinf.as<u8>(), n_groups, out_form))
+        return rc;
+    D2H(ctx, out, dout.p, n_groups * wo);
+    if (inf) D2H(ctx, inf, dinf.p, n_groups);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_multiply_many_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, int m,
+                                               uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
+    return multiply_many_host<false>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+}
+extern "C" int32_t cheetah_multiply_many_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
+                                                       int m, uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
+    return multiply_many_host<true>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+}
+extern "C" int32_t cheetah_multiply_double_with_basepoint_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
+                                                                        const uint8_t* scalars64, uint64_t* out, uint8_t* inf,
+                                                                        size_t n, int out_form) {
+    return multiply_many_host<true>(ctx, pts, in_form, scalars64, 1, 1, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_is_torsion_free_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, CHEETAH_AFFINE)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!pts || !flags) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144;
+    DevBuf dp, df;
+    HIP_TRY(ctx, dp.alloc(n * wi));
+    HIP_TRY(ctx, df.alloc(n));
+    H2D(ctx, dp.p, pts, n * wi);
+    if (int32_t rc = cheetah_is_torsion_free_batch_dev(ctx, dp.as<u64>(), in_form, df.as<u8>(), n)) return rc;
+    D2H(ctx, flags, df.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_clear_cofactor_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint64_t* out, uint8_t* inf,
+                                                size_t n, int out_form) {
+    CHECK_CTX(ctx);
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (!pts || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144, wo = out_form == CHEETAH_AFFINE ? 96 : 144;
+    DevBuf dp, dout, dinf;
+    HIP_TRY(ctx, dp.alloc(n * wi));
+    HIP_TRY(ctx, dout.alloc(n * wo));
+    HIP_TRY(ctx, dinf.alloc(n));
+    H2D(ctx, dp.p, pts, n * wi);
+    if (int32_t rc = cheetah_clear_cofactor_batch_dev(ctx, dp.as<u64>(), in_form, dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
+    D2H(ctx, out, dout.p, n * wo);
+    if (inf) D2H(ctx, inf, dinf.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
 // ------------------------------------------------------- tables, synth -----
 
 extern "C" int32_t cheetah_read_table(cheetah_ctx* ctx, int which, uint64_t* out_xy, size_t max_points) {
@@ -474,6 +691,9 @@ extern "C" int32_t cheetah_read_table(cheetah_ctx* ctx, int which, uint64_t* out
     } else if (which == 2) {
         off = offsetof(DeviceTables, basepoint_lookup);
         pts = 128;
+    } else if (which == 3) {
+        off = offsetof(DeviceTables, odd_multiples);
+        pts = 64;
     } else {
         return fail(ctx, CHEETAH_ERR_INVALID, "unknown table");
     }

@@ -18,6 +18,7 @@ struct DeviceTables {
     u64 minus_shift_4[12];       // MINUS_SHIFT_POINT_ARRAY[4]   = -2^4 S            src/constants.rs:76-90
     u64 minus_shift_256[12];     // MINUS_SHIFT_POINT_ARRAY[256] = -2^256 S
     u64 basepoint_lookup[128 * 12];  // BASEPOINT_LOOKUP: LookupTable<128> = [G .. 128 G], x|y  src/constants.rs:26-27
+    u64 odd_multiples[64 * 12];      // ODD_MULTIPLES_BASEPOINT: NafLookupTable<64> = [G, 3G .. 127 G]  src/constants.rs:32-33
 };
 
 // ---- AoS <-> register helpers --------------------------------------------
@@ -57,9 +58,12 @@ CH_DEV void store_proj(u64* out, u8* inf, size_t i, const Proj& p) {
     if (inf) inf[i] = fp6_is_zero(p.z) ? 1 : 0;
 }
 // out_form 0: normalise (one Fp6 inversion per lane), 1: the projective representative as is
+// out_form 3: only the identity flag (is_identity() of the representative, z == 0)
 template <int OUT_FORM>
 CH_DEV void emit_point(u64* out, u8* inf, size_t i, const Proj& p) {
-    if (OUT_FORM == 0)
+    if (OUT_FORM == 3)
+        inf[i] = fp6_is_zero(p.z) ? 1 : 0;
+    else if (OUT_FORM == 0)
         store_affine(out, inf, i, affine_from_proj(p));
     else
         store_proj(out, inf, i, p);
@@ -73,7 +77,9 @@ CH_DEV void emit_point(u64* out, u8* inf, size_t i, const MJac& p) {
     j.x = p.x;
     j.y = p.y;
     j.z = p.z;
-    if (OUT_FORM == 0)
+    if (OUT_FORM == 3)
+        inf[i] = fp6_is_zero(p.z) ? 1 : 0;
+    else if (OUT_FORM == 0)
         store_affine(out, inf, i, affine_from_jac(j));
     else
         store_proj(out, inf, i, j);
@@ -98,9 +104,10 @@ template <> struct Ladder<MJac> {
 // Table construction (context creation).  Thread t < 32 builds LookupTable<8> of
 // 256^t G (src/lookup.rs:164-173, :25-37); thread 32 builds -2^4 S and -2^256 S
 // (src/constants.rs:80-90); thread 64 + e builds entry (e + 1) G of
-// BASEPOINT_LOOKUP (src/constants.rs:26-27).  Entries are affine, hence
+// BASEPOINT_LOOKUP (src/constants.rs:26-27); thread 192 + e builds entry (2e + 1) G of
+// ODD_MULTIPLES_BASEPOINT (src/constants.rs:32-33).  Entries are affine, hence
 // independent of how they were computed.
-constexpr int BUILD_TABLES_THREADS = 192;
+constexpr int BUILD_TABLES_THREADS = 256;
 __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTables* tab, const u64* gen_xy, const u64* shift_xy) {
     const int t = threadIdx.x;
     if (t < 32) {
@@ -123,7 +130,8 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
         }
         store_affine(tab->minus_shift_256, nullptr, 0, affine_from_proj(cur));
     } else if (t >= 64) {
-        const int m = t - 63;  // 1 .. 128, by left-to-right double-and-add with the complete formulas
+        const bool odd = t >= 192;
+        const int m = odd ? 2 * (t - 192) + 1 : t - 63;  // multiplier, by left-to-right double-and-add with the complete formulas
         const Proj g = proj_from_affine(load_affine(gen_xy));
         Proj acc = proj_identity();
         for (int b = 7; b >= 0; b--) {
@@ -131,7 +139,10 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
             Proj sum = proj_add(acc, g);
             if ((m >> b) & 1) acc = sum;
         }
-        store_affine(tab->basepoint_lookup, nullptr, (size_t)(m - 1), affine_from_proj(acc));
+        if (odd)
+            store_affine(tab->odd_multiples, nullptr, (size_t)(t - 192), affine_from_proj(acc));
+        else
+            store_affine(tab->basepoint_lookup, nullptr, (size_t)(m - 1), affine_from_proj(acc));
     }
 }
 
@@ -570,7 +581,7 @@ template <class ACC, int IN_FORM, int OUT_FORM>
 __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n,
-                                                            u64* __restrict__ scratch) {
+                                                            u64* __restrict__ scratch, int uniform_scalar) {
     __shared__ i8 s_naf[256 * BLOCK];
     const int t = threadIdx.x;
     u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
@@ -584,7 +595,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
         const bool active = i < n;
         const size_t ii = active ? i : n - 1;
         u64 k[4];
-        load_scalar(scalars, ii, k);
+        load_scalar(scalars, uniform_scalar ? 0 : ii, k);  // uniform: is_torsion_free / clear_cofactor (one fixed scalar)
         __syncthreads();
         recode_wnaf(k, 5, s_naf, t);
         __syncthreads();
@@ -625,6 +636,145 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
         }
         acc = Ladder<ACC>::add(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Multi-scalar (Straus) ladders: out[g] = sum_{j<m} k[g][j] * P[g][j], shared
+// doublings, one window table per point, additions in index order.
+//   ct      ProjectivePoint / JacobianPoint::multiply_many  src/curve/projective.rs:817-832, src/curve/jacobian.rs:807-823
+//           (multiply_double, :666-685 / :653-673, is the case m = 2)
+//   vartime multiply_many_vartime / multiply_double_vartime  src/curve/projective.rs:693-742, :840-869
+//           with_basepoint: multiply_double_with_basepoint_vartime (:756-809): one more scalar per
+//           group, recoded with a width-8 NAF, multiplying G through ODD_MULTIPLES_BASEPOINT
+// Per-workgroup scratch: tables [m][16][12][BLOCK], z / prefix [16][6][BLOCK] each,
+// identity masks [m][BLOCK], digits [ns][256][BLOCK] bytes.
+struct ManyScratch {
+    static constexpr size_t TAB = (size_t)16 * 12 * BLOCK;
+    static constexpr size_t ZP = (size_t)16 * 6 * BLOCK;
+    static size_t words(int m, int ns) { return (size_t)m * TAB + 2 * ZP + (size_t)m * BLOCK + (size_t)ns * 256 * BLOCK / 8; }
+};
+
+template <class ACC, int IN_FORM, int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
+                                                            const u8* __restrict__ scalars, u64* __restrict__ out,
+                                                            u8* __restrict__ inf, size_t n_groups, int m,
+                                                            u64* __restrict__ scratch, size_t words_per_block) {
+    const int t = threadIdx.x;
+    u64* s_tabs = scratch + (size_t)blockIdx.x * words_per_block;
+    u64* s_z = s_tabs + (size_t)m * ManyScratch::TAB;
+    u64* s_prefix = s_z + ManyScratch::ZP;
+    u32* s_ident = reinterpret_cast<u32*>(s_prefix + ManyScratch::ZP);
+    i8* s_dig = reinterpret_cast<i8*>(s_prefix + ManyScratch::ZP + (size_t)m * BLOCK);
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t nround = (n_groups + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t g = round * BLOCK + t;
+        const bool active = g < n_groups;
+        const size_t gg = active ? g : n_groups - 1;
+        bool wide = false;
+        for (int j = 0; j < m; j++) {
+            u64 k[4];
+            load_scalar(scalars, gg * m + j, k);
+            recode_radix16(k, s_dig + (size_t)j * 256 * BLOCK, t);
+            wide = wide || (k[3] >> 60) > 7;
+        }
+        const int n_entries = __any(wide) ? 16 : 8;
+        for (int j = 0; j < m; j++) {
+            const Proj p = load_input_point<IN_FORM>(pts, gg * m + j);
+            s_ident[j * BLOCK + t] = build_table<false>(p, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
+        }
+        ACC acc = Ladder<ACC>::from_affine(shift);
+        for (int w = 63; w >= 0; w--) {
+            for (int r = 0; r < 4; r++) acc = Ladder<ACC>::dbl(acc);
+            for (int j = 0; j < m; j++)
+                acc = Ladder<ACC>::add(acc, scan_lookup(s_tabs + (size_t)j * ManyScratch::TAB, n_entries, s_ident[j * BLOCK + t],
+                                                        s_dig[((size_t)j * 256 + w) * BLOCK + t], t));
+        }
+        acc = Ladder<ACC>::add(acc, mshift);
+        if (active) emit_point<OUT_FORM>(out, inf, g, acc);
+    }
+}
+
+template <class ACC, int IN_FORM, int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_vartime(const DeviceTables* __restrict__ tab,
+                                                                 const u64* __restrict__ pts, const u8* __restrict__ scalars,
+                                                                 u64* __restrict__ out, u8* __restrict__ inf, size_t n_groups,
+                                                                 int m, int with_basepoint, u64* __restrict__ scratch,
+                                                                 size_t words_per_block) {
+    const int t = threadIdx.x;
+    const int ns = m + (with_basepoint ? 1 : 0);
+    u64* s_tabs = scratch + (size_t)blockIdx.x * words_per_block;
+    u64* s_z = s_tabs + (size_t)m * ManyScratch::TAB;
+    u64* s_prefix = s_z + ManyScratch::ZP;
+    u32* s_ident = reinterpret_cast<u32*>(s_prefix + ManyScratch::ZP);
+    i8* s_dig = reinterpret_cast<i8*>(s_prefix + ManyScratch::ZP + (size_t)m * BLOCK);
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t nround = (n_groups + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t g = round * BLOCK + t;
+        const bool active = g < n_groups;
+        const size_t gg = active ? g : n_groups - 1;
+        for (int j = 0; j < ns; j++) {
+            u64 k[4];
+            load_scalar(scalars, gg * ns + j, k);
+            recode_wnaf(k, j < m ? 5 : 8, s_dig + (size_t)j * 256 * BLOCK, t);
+        }
+        for (int j = 0; j < m; j++) {
+            const Proj p = load_input_point<IN_FORM>(pts, gg * m + j);
+            s_ident[j * BLOCK + t] = build_table<true>(p, 8, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
+        }
+        ACC acc = Ladder<ACC>::from_affine(shift);
+        // Same wave-level parking as k_multiply_vartime; a lane may now owe several
+        // additions at one position (one per table, in index order): after each it goes
+        // on scanning the remaining tables of that position before it may double again.
+        int pos = 255, cur = 0, j = ns, pd = 0, pj = 0;
+        for (;;) {
+            const bool can = pd == 0 && j >= ns && pos >= 0;
+            const u64 m_can = __builtin_amdgcn_ballot_w64(can);
+            const u64 m_pend = __builtin_amdgcn_ballot_w64(pd != 0);
+            if (m_can == 0 && m_pend == 0) break;
+            bool rescan = false;
+            if (m_pend != 0 && (__builtin_popcountll(m_pend) >= 48 || m_can == 0)) {
+                if (pd != 0) {
+                    const int e = (pd < 0 ? -pd : pd) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
+                    Affine q;
+                    if (pj < m) {
+                        const u64* tb = s_tabs + (size_t)pj * ManyScratch::TAB;
+                        q.x = sc_load(tb, e, 0, t, 12);
+                        q.y = sc_load(tb, e, 6, t, 12);
+                        q.inf = (s_ident[pj * BLOCK + t] >> e) & 1;
+                    } else {
+                        q = load_affine(tab->odd_multiples + 12 * e);
+                    }
+                    acc = Ladder<ACC>::add(acc, affine_cond_neg(q, pd < 0));
+                    pd = 0;
+                    rescan = true;
+                }
+            } else if (can) {
+                acc = Ladder<ACC>::dbl(acc);
+                cur = pos;
+                pos--;
+                j = 0;
+                rescan = true;
+            }
+            if (rescan) {
+                while (j < ns) {
+                    const int d = s_dig[((size_t)j * 256 + cur) * BLOCK + t];
+                    j++;
+                    if (d != 0) {
+                        pd = d;
+                        pj = j - 1;
+                        break;
+                    }
+                }
+            }
+        }
+        acc = Ladder<ACC>::add(acc, mshift);
+        if (active) emit_point<OUT_FORM>(out, inf, g, acc);
     }
 }
 

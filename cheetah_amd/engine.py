@@ -219,9 +219,76 @@ class Engine:
         (src/curve/jacobian.rs:619-649), chosen by the forms as in multiply_batch."""
         return self._multiply(True, pts, scalars, in_form, out_form, out, inf)
 
+    # -- multi-scalar ladders, subgroup check, cofactor clearing ----------------------
+    def _many(self, fname, pts, scalars, m, ns, in_form, out_form):
+        w, wi = self._out_width(out_form), self._out_width(in_form)
+        if _is_torch(pts):
+            p, s = self._dev(pts, 8, wi), self._dev(scalars, 1, 32)
+            if s.shape[0] % ns or p.shape[0] * ns != s.shape[0] * m:
+                raise ValueError("need m points and %d scalars per group" % ns)
+            n = s.shape[0] // ns
+            out, inf = self._empty((n, w), torch.uint64), self._empty((n,), torch.uint8)
+            self._use_torch_stream()
+            f = getattr(self._lib, fname + "_dev")
+            args = (self._h, p.data_ptr(), in_form, s.data_ptr()) + ((m,) if "many" in fname else ()) + (out.data_ptr(), inf.data_ptr(), n, out_form)
+            self._check(f(*args))
+            return out, inf
+        p, s = self._np(pts, np.uint64, wi), self._np(scalars, np.uint8, 32)
+        if len(s) % ns or len(p) * ns != len(s) * m:
+            raise ValueError("need m points and %d scalars per group" % ns)
+        n = len(s) // ns
+        out, inf = np.empty((n, w), np.uint64), np.empty(n, np.uint8)
+        f = getattr(self._lib, fname)
+        args = (self._h, p.ctypes.data, in_form, s.ctypes.data) + ((m,) if "many" in fname else ()) + (out.ctypes.data, inf.ctypes.data, n, out_form)
+        self._check(f(*args))
+        return out, inf
+
+    def multiply_many_batch(self, pts, scalars, m, in_form=AFFINE, out_form=AFFINE):
+        """out[g] = sum_j scalars[g*m + j] * pts[g*m + j], constant time (multiply_many,
+        src/curve/projective.rs:817-832, src/curve/jacobian.rs:807-823; m = 2: multiply_double)."""
+        return self._many("cheetah_multiply_many_batch", pts, scalars, m, m, in_form, out_form)
+
+    def multiply_many_vartime_batch(self, pts, scalars, m, in_form=AFFINE, out_form=AFFINE):
+        """Variable-time form (multiply_many_vartime, src/curve/projective.rs:840-869; m = 2: multiply_double_vartime)."""
+        return self._many("cheetah_multiply_many_vartime_batch", pts, scalars, m, m, in_form, out_form)
+
+    def multiply_double_with_basepoint_vartime_batch(self, pts, scalars, in_form=AFFINE, out_form=AFFINE):
+        """out[i] = scalars[2i] * pts[i] + scalars[2i + 1] * G (src/curve/projective.rs:756-809)."""
+        return self._many("cheetah_multiply_double_with_basepoint_vartime_batch", pts, scalars, 1, 2, in_form, out_form)
+
+    def is_torsion_free_batch(self, pts, in_form=AFFINE):
+        """flags[i] = (q * pts[i]).is_identity()   (is_torsion_free, src/curve/projective.rs:885-893)"""
+        wi = self._out_width(in_form)
+        if _is_torch(pts):
+            p = self._dev(pts, 8, wi)
+            flags = self._empty((p.shape[0],), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_is_torsion_free_batch_dev(self._h, p.data_ptr(), in_form, flags.data_ptr(), p.shape[0]))
+            return flags
+        p = self._np(pts, np.uint64, wi)
+        flags = np.empty(len(p), np.uint8)
+        self._check(self._lib.cheetah_is_torsion_free_batch(self._h, p.ctypes.data, in_form, flags.ctypes.data, len(p)))
+        return flags
+
+    def clear_cofactor_batch(self, pts, in_form=AFFINE, out_form=AFFINE):
+        """out[i] = h * pts[i] through the vartime ladder (clear_cofactor, src/curve/projective.rs:872-881)."""
+        w, wi = self._out_width(out_form), self._out_width(in_form)
+        if _is_torch(pts):
+            p = self._dev(pts, 8, wi)
+            n = p.shape[0]
+            out, inf = self._empty((n, w), torch.uint64), self._empty((n,), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_clear_cofactor_batch_dev(self._h, p.data_ptr(), in_form, out.data_ptr(), inf.data_ptr(), n, out_form))
+            return out, inf
+        p = self._np(pts, np.uint64, wi)
+        n = len(p)
+        out, inf = np.empty((n, w), np.uint64), np.empty(n, np.uint8)
+        self._check(self._lib.cheetah_clear_cofactor_batch(self._h, p.ctypes.data, in_form, out.ctypes.data, inf.ctypes.data, n, out_form))
+        return out, inf
+
     # -- tables / synthetic inputs / diagnostics -------------------------------------
     def read_table(self, which):
-        n = {0: 256, 1: 3, 2: 128}[which]
+        n = {0: 256, 1: 3, 2: 128, 3: 64}[which]
         out = np.empty((n, 12), np.uint64)
         self._check(self._lib.cheetah_read_table(self._h, which, out.ctypes.data, n))
         return out
@@ -273,6 +340,14 @@ def default_engine(device=0):
     return _default[device]
 
 
+
+def _interleave(a, b):
+    """[a0, b0, a1, b1, ...]: the per-group layout of the multi-scalar entry points."""
+    if _is_torch(a):
+        return torch.stack([a, b], dim=1).reshape(2 * a.shape[0], a.shape[1]).contiguous()
+    return np.stack([a, b], axis=1).reshape(2 * len(a), a.shape[1])
+
+
 class Fp6:
     @staticmethod
     def mul_batch(a, b, engine=None):
@@ -293,6 +368,34 @@ class ProjectivePoint:
         return (engine or default_engine()).batch_normalize(p, PROJECTIVE)
 
     @staticmethod
+    def multiply_double_batch(lhs, rhs, by_lhs, by_rhs, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).multiply_many_batch(_interleave(lhs, rhs), _interleave(by_lhs, by_rhs), 2, in_form, out_form)
+
+    @staticmethod
+    def multiply_double_vartime_batch(lhs, rhs, by_lhs, by_rhs, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).multiply_many_vartime_batch(_interleave(lhs, rhs), _interleave(by_lhs, by_rhs), 2, in_form, out_form)
+
+    @staticmethod
+    def multiply_double_with_basepoint_vartime_batch(points, by_self, by_basepoint, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).multiply_double_with_basepoint_vartime_batch(points, _interleave(by_self, by_basepoint), in_form, out_form)
+
+    @staticmethod
+    def multiply_many_batch(points, scalars, m, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).multiply_many_batch(points, scalars, m, in_form, out_form)
+
+    @staticmethod
+    def multiply_many_vartime_batch(points, scalars, m, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).multiply_many_vartime_batch(points, scalars, m, in_form, out_form)
+
+    @staticmethod
+    def is_torsion_free_batch(points, in_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).is_torsion_free_batch(points, in_form)
+
+    @staticmethod
+    def clear_cofactor_batch(points, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
+        return (engine or default_engine()).clear_cofactor_batch(points, in_form, out_form)
+
+    @staticmethod
     def multiply_batch(points, scalars, in_form=PROJECTIVE, out_form=PROJECTIVE, engine=None):
         return (engine or default_engine()).multiply_batch(points, scalars, in_form, out_form)
 
@@ -305,6 +408,34 @@ class JacobianPoint:
     @staticmethod
     def batch_normalize(p, engine=None):
         return (engine or default_engine()).batch_normalize(p, JACOBIAN)
+
+    @staticmethod
+    def multiply_double_batch(lhs, rhs, by_lhs, by_rhs, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_many_batch(_interleave(lhs, rhs), _interleave(by_lhs, by_rhs), 2, in_form, out_form)
+
+    @staticmethod
+    def multiply_double_vartime_batch(lhs, rhs, by_lhs, by_rhs, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_many_vartime_batch(_interleave(lhs, rhs), _interleave(by_lhs, by_rhs), 2, in_form, out_form)
+
+    @staticmethod
+    def multiply_double_with_basepoint_vartime_batch(points, by_self, by_basepoint, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_double_with_basepoint_vartime_batch(points, _interleave(by_self, by_basepoint), in_form, out_form)
+
+    @staticmethod
+    def multiply_many_batch(points, scalars, m, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_many_batch(points, scalars, m, in_form, out_form)
+
+    @staticmethod
+    def multiply_many_vartime_batch(points, scalars, m, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).multiply_many_vartime_batch(points, scalars, m, in_form, out_form)
+
+    @staticmethod
+    def is_torsion_free_batch(points, in_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).is_torsion_free_batch(points, in_form)
+
+    @staticmethod
+    def clear_cofactor_batch(points, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):
+        return (engine or default_engine()).clear_cofactor_batch(points, in_form, out_form)
 
     @staticmethod
     def multiply_batch(points, scalars, in_form=JACOBIAN, out_form=JACOBIAN, engine=None):

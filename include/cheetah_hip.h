@@ -129,10 +129,53 @@ int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx *ctx, const uint64_t *pts
                                            const uint8_t *scalars32, uint64_t *out, uint8_t *inf, size_t n,
                                            int out_form);
 
+/* ---- multi-scalar (Straus) ladders -----------------------------------------
+ * out[g] = sum_{j < m} scalars[g*m + j] * pts[g*m + j]   (points and scalars interleaved per group)
+ * cheetah_multiply_many_batch          {Projective,Jacobian}Point::multiply_many
+ *                                      src/curve/projective.rs:817-832, src/curve/jacobian.rs:807-823;
+ *                                      m = 2 is multiply_double (src/curve/projective.rs:666-685, jacobian.rs:653-673)
+ * cheetah_multiply_many_vartime_batch  multiply_many_vartime (src/curve/projective.rs:840-869, jacobian.rs:831-858);
+ *                                      m = 2 is multiply_double_vartime (:693-742 / :681-731, quirk Q1 included:
+ *                                      both always run 256 doublings)
+ * cheetah_multiply_double_with_basepoint_vartime_batch
+ *                                      out[i] = s[2i] * pts[i] + s[2i+1] * G through ODD_MULTIPLES_BASEPOINT with a
+ *                                      width-8 NAF (src/curve/projective.rs:756-809, src/curve/jacobian.rs:745-799)
+ * Forms select Projective / Jacobian as for cheetah_multiply_batch (AffinePoint's wrappers give the same
+ * affine point whichever ladder runs, src/curve/affine.rs:388-452).  1 <= m <= CHEETAH_MAX_MANY. */
+#define CHEETAH_MAX_MANY 64
+int32_t cheetah_multiply_many_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32, int m,
+                                    uint64_t *out, uint8_t *inf, size_t n_groups, int out_form);
+int32_t cheetah_multiply_many_vartime_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
+                                            int m, uint64_t *out, uint8_t *inf, size_t n_groups, int out_form);
+int32_t cheetah_multiply_double_with_basepoint_vartime_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form,
+                                                             const uint8_t *scalars64, uint64_t *out, uint8_t *inf,
+                                                             size_t n, int out_form);
+int32_t cheetah_multiply_many_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32, int m,
+                                        uint64_t *out, uint8_t *inf, size_t n_groups, int out_form);
+int32_t cheetah_multiply_many_vartime_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form,
+                                                const uint8_t *scalars32, int m, uint64_t *out, uint8_t *inf,
+                                                size_t n_groups, int out_form);
+int32_t cheetah_multiply_double_with_basepoint_vartime_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form,
+                                                                 const uint8_t *scalars64, uint64_t *out, uint8_t *inf,
+                                                                 size_t n, int out_form);
+
+/* ---- subgroup check, cofactor clearing ---------------------------------------
+ * flags[i] = is_torsion_free(pts[i]) = (q * pts[i]).is_identity() through the vartime ladder
+ *            (src/curve/projective.rs:885-893, src/curve/jacobian.rs:874-882, src/curve/affine.rs:463-467)
+ * out[i]   = clear_cofactor(pts[i]) = multiply_vartime(pts[i], h)
+ *            (src/curve/projective.rs:872-881, src/curve/jacobian.rs:861-870, src/curve/affine.rs:455-459) */
+int32_t cheetah_is_torsion_free_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint8_t *flags, size_t n);
+int32_t cheetah_clear_cofactor_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint64_t *out, uint8_t *inf,
+                                     size_t n, int out_form);
+int32_t cheetah_is_torsion_free_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint8_t *flags, size_t n);
+int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint64_t *out, uint8_t *inf,
+                                         size_t n, int out_form);
+
 /* ---- precomputed tables (read back for inspection / tests) ----------------
  * which: 0 = BASEPOINT_TABLE (256 affine points, table-major, src/lookup.rs:136),
  *        1 = shift point S, -2^4 S, -2^256 S (3 affine points, src/constants.rs:43-90),
- *        2 = BASEPOINT_LOOKUP = [G .. 128 G] (128 affine points, src/constants.rs:26-27). */
+ *        2 = BASEPOINT_LOOKUP = [G .. 128 G] (128 affine points, src/constants.rs:26-27),
+ *        3 = ODD_MULTIPLES_BASEPOINT = [G, 3G .. 127 G] (64 affine points, src/constants.rs:32-33). */
 int32_t cheetah_read_table(cheetah_ctx *ctx, int which, uint64_t *out_xy, size_t max_points);
 
 /* ---- synthetic inputs generated on the device (bench / tests) -------------

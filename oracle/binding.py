@@ -107,6 +107,8 @@ def lib():
         "ora_mul_by_generator_batch": (None, [u8p, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_multiply_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_multiply_vartime_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
+        "ora_odd_multiples_basepoint": (C.POINTER(C.c_uint64), []),
+        "ora_multiply_many_batch": (None, [u64p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_jac_batch_normalize_chunked": (None, [u64p, C.c_size_t, C.c_size_t, u64p, u8p]),
         "ora_proj_batch_normalize_chunked": (None, [u64p, C.c_size_t, C.c_size_t, u64p, u8p]),
     }
@@ -197,6 +199,17 @@ def multiply_batch(pts, in_form, scalars, out_form=0, vartime=False):
     out, inf = _out_bufs(len(s), out_form)
     f = lib().ora_multiply_vartime_batch if vartime else lib().ora_multiply_batch
     f(p, in_form, s, out, inf, len(s), out_form)
+    return out, inf
+
+
+def multiply_many_batch(pts, in_form, scalars, m, out_form=0, vartime=False, with_basepoint=False):
+    """out[g] = sum_j scalars[g, j] * pts[g, j] (+ scalars[g, m] * G when with_basepoint)."""
+    ns = m + (1 if with_basepoint else 0)
+    s = _u8(scalars).reshape(-1, ns * 32)
+    n = len(s)
+    p = _u64(pts).reshape(n * m, 12 if in_form == 0 else 18)
+    out, inf = _out_bufs(n, out_form)
+    lib().ora_multiply_many_batch(p, in_form, s, m, int(vartime), int(with_basepoint), out, inf, n, out_form)
     return out, inf
 
 

@@ -1037,7 +1037,9 @@ static affine G_MINUS_SHIFT[257];    /* src/constants.rs:76-90 */
 static affine G_BASEPOINT_TABLE[32][8]; /* src/constants.rs:21-22, src/lookup.rs:164-173 */
 static affine G_BASEPOINT_LOOKUP[128]; /* src/constants.rs:26-27 */
 static u64 G_FLAT_MINUS_SHIFT[257 * 12], G_FLAT_BPT[32 * 8 * 12], G_FLAT_BPL[128 * 12], G_FLAT_SHIFT[12], G_FLAT_GEN[12];
-static int g_init_done = 0, g_bpl_done = 0;
+static affine G_ODD_MULTIPLES[64];   /* ODD_MULTIPLES_BASEPOINT: NafLookupTable<64> of G, src/constants.rs:32-33 */
+static u64 G_FLAT_ODD[64 * 12];
+static int g_init_done = 0, g_bpl_done = 0, g_odd_done = 0;
 
 static void ora_init(void) {
     if (g_init_done) return;
@@ -1079,6 +1081,22 @@ static void ora_init_bpl(void) {
             g_bpl_done = 1;
         }
     }
+}
+static void ora_init_odd(void) {
+    if (g_odd_done) return;
+#pragma omp critical(ora_init_odd_lock)
+    {
+        if (!g_odd_done) {
+            naf_table_from_proj(proj_from_affine(GENERATOR), 64, G_ODD_MULTIPLES);
+            for (int i = 0; i < 64; i++) affine_store(G_FLAT_ODD + 12 * i, NULL, G_ODD_MULTIPLES[i]);
+            __sync_synchronize();
+            g_odd_done = 1;
+        }
+    }
+}
+const u64 *ora_odd_multiples_basepoint(void) {
+    ora_init_odd();
+    return G_FLAT_ODD;
 }
 const u64 *ora_basepoint_table(void) {
     ora_init();
@@ -1308,6 +1326,101 @@ void ora_multiply_vartime_batch(const u64 *pts, int in_form, const uint8_t *scal
         proj p = load_in_point(pts, in_form, i);
         emit_point(jac ? jac_multiply_vartime(p, scalars + 32 * i) : proj_multiply_vartime(p, scalars + 32 * i), jac, out, out_inf,
                    i, out_form);
+    }
+}
+
+
+/* ---- multi-scalar ladders (Straus: shared doublings, one table per point) ---- */
+
+#define MAXMANY 64
+
+/* ProjectivePoint::multiply_many, src/curve/projective.rs:817-832; multiply_double
+ * (:666-685) is the same sequence with two points. */
+static proj proj_multiply_many(const proj *pts, const uint8_t *scalars, int m) {
+    ora_init();
+    static _Thread_local affine tables[MAXMANY][16];
+    static _Thread_local int8_t digits[MAXMANY][64];
+    for (int j = 0; j < m; j++) {
+        lookup_table_from_proj(pts[j], 16, tables[j]);
+        ora_bytes_to_radix_16(scalars + 32 * j, digits[j]);
+    }
+    proj acc = proj_from_affine(SHIFT_POINT);
+    for (int i = 63; i >= 0; i--) {
+        for (int k = 0; k < 4; k++) acc = proj_double_unchecked(acc);
+        for (int j = 0; j < m; j++) acc = proj_add_mixed_unchecked(acc, lookup_get_point(tables[j], 16, digits[j][i]));
+    }
+    return proj_add_mixed_unchecked(acc, G_MINUS_SHIFT[256]);
+}
+/* JacobianPoint::multiply_many, src/curve/jacobian.rs:807-823; multiply_double :653-673 */
+static proj jac_multiply_many(const proj *pts, const uint8_t *scalars, int m) {
+    ora_init();
+    static _Thread_local affine tables[MAXMANY][16];
+    static _Thread_local int8_t digits[MAXMANY][64];
+    for (int j = 0; j < m; j++) {
+        lookup_table_from_proj(proj_from_affine(affine_from_jac(pts[j])), 16, tables[j]);
+        ora_bytes_to_radix_16(scalars + 32 * j, digits[j]);
+    }
+    mjac acc = mjac_from_affine(SHIFT_POINT);
+    for (int i = 63; i >= 0; i--) {
+        for (int k = 0; k < 4; k++) acc = mjac_double_unchecked(acc);
+        for (int j = 0; j < m; j++) acc = mjac_add_mixed_unchecked(acc, lookup_get_point(tables[j], 16, digits[j][i]));
+    }
+    return jac_from_mjac(mjac_add_mixed_unchecked(acc, G_MINUS_SHIFT[256]));
+}
+
+/* The vartime multi-scalar ladders.  multiply_many_vartime always runs 256 doublings
+ * (src/curve/projective.rs:840-869, src/curve/jacobian.rs:831-858); multiply_double_vartime
+ * and multiply_double_with_basepoint_vartime carry quirk Q1 (their "skip unset digits"
+ * loop tests index i, which stays 255: src/curve/projective.rs:703-709, :765-771), so they
+ * too run 256 doublings and correct with MINUS_SHIFT_POINT_ARRAY[256].
+ * with_basepoint: the last scalar multiplies G through ODD_MULTIPLES_BASEPOINT with a
+ * width-8 NAF (src/curve/projective.rs:756-809). */
+static affine naf_pick(const affine *table, int8_t d) { /* NafLookupTable::get_point(x) = table[x / 2], src/naf_lookup.rs:87-92 */
+    return d > 0 ? table[(size_t)d / 2] : affine_neg(table[(size_t)(-d) / 2]);
+}
+static proj multiply_many_vartime_generic(const proj *pts, const uint8_t *scalars, int m, int with_basepoint, int jac) {
+    ora_init();
+    if (with_basepoint) ora_init_odd();
+    static _Thread_local affine tables[MAXMANY][8];
+    static _Thread_local int8_t digits[MAXMANY + 1][256];
+    for (int j = 0; j < m; j++) {
+        naf_table_from_proj(jac ? proj_from_affine(affine_from_jac(pts[j])) : pts[j], 8, tables[j]);
+        ora_bytes_to_wnaf_vartime(scalars + 32 * j, 5, digits[j]);
+    }
+    if (with_basepoint) ora_bytes_to_wnaf_vartime(scalars + 32 * m, 8, digits[m]);
+    proj pacc = proj_from_affine(SHIFT_POINT);
+    mjac macc = mjac_from_affine(SHIFT_POINT);
+    for (int i = 255; i >= 0; i--) {
+        if (jac) macc = mjac_double_unchecked(macc); else pacc = proj_double_unchecked(pacc);
+        for (int j = 0; j < m + (with_basepoint ? 1 : 0); j++) {
+            int8_t d = digits[j][i];
+            if (d == 0) continue;
+            affine q = j < m ? naf_pick(tables[j], d) : naf_pick(G_ODD_MULTIPLES, d);
+            if (jac) macc = mjac_add_mixed_unchecked(macc, q); else pacc = proj_add_mixed_unchecked(pacc, q);
+        }
+    }
+    if (jac) return jac_from_mjac(mjac_add_mixed_unchecked(macc, G_MINUS_SHIFT[256]));
+    return proj_add_mixed_unchecked(pacc, G_MINUS_SHIFT[256]);
+}
+
+/* Batch driver: group g uses points / scalars [g*m, (g+1)*m) (with_basepoint: m points and
+ * m + 1 scalars per group, the last one for G).  Forms as in ora_multiply_batch. */
+void ora_multiply_many_batch(const u64 *pts, int in_form, const uint8_t *scalars, int m, int vartime, int with_basepoint,
+                             u64 *out, uint8_t *out_inf, size_t n_groups, int out_form) {
+    ora_init();
+    const int jac = !(in_form == 1 || out_form == 1);
+    const int ns = m + (with_basepoint ? 1 : 0);
+#pragma omp parallel for schedule(static)
+    for (size_t g = 0; g < n_groups; g++) {
+        proj p[MAXMANY];
+        for (int j = 0; j < m; j++) p[j] = load_in_point(pts, in_form, g * (size_t)m + j);
+        const uint8_t *sc = scalars + 32 * g * (size_t)ns;
+        proj r;
+        if (vartime)
+            r = multiply_many_vartime_generic(p, sc, m, with_basepoint, jac);
+        else
+            r = jac ? jac_multiply_many(p, sc, m) : proj_multiply_many(p, sc, m);
+        emit_point(r, jac, out, out_inf, g, out_form);
     }
 }
 

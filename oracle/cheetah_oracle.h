@@ -98,6 +98,7 @@ void ora_naf_table_from_proj(const uint64_t *p, int n_entries, uint64_t *out_xy,
 /* global tables built on first use (lazy_static)                                 src/constants.rs:18-90 */
 const uint64_t *ora_basepoint_table(void);       /* 32*8 affine points, 12 limbs each (no identities) */
 const uint64_t *ora_basepoint_lookup(void);      /* LookupTable<128> of G, 128*12 limbs */
+const uint64_t *ora_odd_multiples_basepoint(void); /* NafLookupTable<64> of G: G, 3G, ..., 127G; 64*12 limbs (src/constants.rs:32-33) */
 const uint64_t *ora_minus_shift_point_array(void); /* 257 affine points, 12 limbs each */
 const uint64_t *ora_shift_point_affine(void);    /* 12 limbs */
 const uint64_t *ora_generator_affine(void);      /* 12 limbs */
@@ -127,6 +128,13 @@ void ora_multiply_batch(const uint64_t *pts, int in_form, const uint8_t *scalars
                         uint8_t *out_inf, size_t n, int out_form);
 void ora_multiply_vartime_batch(const uint64_t *pts, int in_form, const uint8_t *scalars, uint64_t *out,
                                 uint8_t *out_inf, size_t n, int out_form);
+/* Multi-scalar (Straus) ladders: out[g] = sum_j scalars[g*ns + j] * pts[g*m + j]  (+ scalars[g*ns + m] * G when
+ * with_basepoint; ns = m + with_basepoint).  vartime = 0: multiply_double / multiply_many
+ * (src/curve/projective.rs:666-685, :817-832, src/curve/jacobian.rs:653-673, :807-823); vartime = 1:
+ * multiply_double_vartime / multiply_many_vartime / multiply_double_with_basepoint_vartime
+ * (src/curve/projective.rs:693-809, :840-869, src/curve/jacobian.rs:681-858).  m <= 64. */
+void ora_multiply_many_batch(const uint64_t *pts, int in_form, const uint8_t *scalars, int m, int vartime, int with_basepoint,
+                             uint64_t *out, uint8_t *out_inf, size_t n_groups, int out_form);
 /* chunked: the reference call is one sequential chain per call; the batch driver
  * issues one reference-shaped call per `chunk` points per thread. */
 void ora_jac_batch_normalize_chunked(const uint64_t *p, size_t n, size_t chunk, uint64_t *out_xy, uint8_t *out_inf);

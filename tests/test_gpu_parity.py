@@ -459,6 +459,96 @@ def test_g_a_b_equals_g_ab_on_gpu(eng):
     assert (host(gab) == host(want)).all() and (host(i1) == host(i2)).all()
 
 
+
+# ------------------------------------------ multi-scalar ladders and checks ----
+
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_multiply_many_vs_oracle(eng, ora, m):
+    """multiply_many / multiply_many_vartime (m = 2: multiply_double*), all forms, the reference's
+    own (X, Y, Z) for projective / Jacobian outputs; and the relation the reference tests:
+    sum_j k_j P_j computed jointly == the sum of separate products (src/curve/projective.rs:1354-1397)."""
+    from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE
+    n = 70
+    sc = synth.scalars(7, n * m)
+    edge = [0, 1, Q - 1, 16, (1 << 255) - 1]
+    for i, k in enumerate(edge):
+        sc[i] = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    aff = _random_points(ora, 83, n * m, "affine")
+    prj = _random_points(ora, 83, n * m, "proj")
+    jac = _random_points(ora, 83, n * m, "jac")
+    aff[9] = [0] * 6 + [1] + [0] * 5
+    prj[9, 12:18] = 0
+    jac[9, 12:18] = 0
+    S = dev(sc)
+    for vartime in (False, True):
+        f = eng.multiply_many_vartime_batch if vartime else eng.multiply_many_batch
+        for in_form, pts, out_forms in ((AFFINE, aff, (AFFINE, PROJECTIVE, JACOBIAN)), (PROJECTIVE, prj, (AFFINE, PROJECTIVE)),
+                                        (JACOBIAN, jac, (AFFINE, JACOBIAN))):
+            for out_form in out_forms:
+                want, winf = ora.multiply_many_batch(pts, in_form, sc, m, out_form, vartime=vartime)
+                got, inf = f(dev(pts), S, m, in_form, out_form)
+                assert (host(got) == want).all() and (host(inf) == winf).all(), (vartime, in_form, out_form)
+    # host-pointer entry point
+    got, inf = eng.multiply_many_batch(aff, sc, m, AFFINE, AFFINE)
+    want, winf = ora.multiply_many_batch(aff, 0, sc, m, 0)
+    assert (got == want).all() and (inf == winf).all()
+    if m == 2:  # a*P + b*P == (a + b)*P
+        P2 = np.repeat(aff[:n], 2, axis=0)
+        got, _ = eng.multiply_many_batch(P2, sc, 2, AFFINE, AFFINE)
+        ab = np.array([list(((int.from_bytes(bytes(sc[2 * i]), "little") + int.from_bytes(bytes(sc[2 * i + 1]), "little")) % Q).to_bytes(32, "little"))
+                       for i in range(n)], np.uint8)
+        red = np.array([int.from_bytes(bytes(sc[2 * i]), "little") < Q and int.from_bytes(bytes(sc[2 * i + 1]), "little") < Q for i in range(n)])
+        single, _ = eng.multiply_batch(aff[:n], ab, AFFINE, AFFINE)
+        assert (got[red] == single[red]).all()
+
+
+def test_multiply_double_with_basepoint_vartime(eng, ora):
+    """a*P + b*G through ODD_MULTIPLES_BASEPOINT (src/curve/projective.rs:756-809); the table itself
+    against the oracle's NafLookupTable<64> of G."""
+    from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE
+    assert (eng.read_table(3) == ora.table("ora_odd_multiples_basepoint", 64)).all()
+    n = 130
+    sc = synth.scalars(8, 2 * n)
+    for i, k in enumerate([0, 0, 1, 0, 0, 1, Q - 1, Q - 1]):
+        sc[i] = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    aff = _random_points(ora, 85, n, "affine")
+    prj = _random_points(ora, 85, n, "proj")
+    jac = _random_points(ora, 85, n, "jac")
+    for in_form, pts, out_forms in ((AFFINE, aff, (AFFINE, JACOBIAN)), (PROJECTIVE, prj, (AFFINE, PROJECTIVE)), (JACOBIAN, jac, (JACOBIAN,))):
+        for out_form in out_forms:
+            want, winf = ora.multiply_many_batch(pts, in_form, sc, 1, out_form, vartime=True, with_basepoint=True)
+            got, inf = eng.multiply_double_with_basepoint_vartime_batch(dev(pts), dev(sc), in_form, out_form)
+            assert (host(got) == want).all() and (host(inf) == winf).all(), (in_form, out_form)
+    got, inf = eng.multiply_double_with_basepoint_vartime_batch(aff, sc, AFFINE, AFFINE)
+    want, winf = ora.multiply_many_batch(aff, 0, sc, 1, 0, vartime=True, with_basepoint=True)
+    assert (got == want).all() and (inf == winf).all()
+
+
+def test_is_torsion_free_and_clear_cofactor(eng, ora, kats):
+    """is_torsion_free / clear_cofactor (src/curve/projective.rs:872-893): G and seeded subgroup points are
+    torsion free, the reference's non-subgroup point (:1407-1425) is not, its cofactor multiple is;
+    clear_cofactor == multiply_vartime by the cofactor bytes, representative included."""
+    from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE
+    g = kats["generator"]["x"] + kats["generator"]["y"]
+    ns = kats["non_subgroup_point"]["x"] + kats["non_subgroup_point"]["y"]
+    sub = _random_points(ora, 87, 100, "affine")
+    pts = np.concatenate([np.array([g, ns, [0] * 6 + [1] + [0] * 5], np.uint64), sub])
+    flags = eng.is_torsion_free_batch(pts, AFFINE)
+    assert list(flags[:3]) == [1, 0, 1] and flags[3:].all()
+    assert (host(eng.is_torsion_free_batch(dev(pts), AFFINE)) == flags).all()
+    prj = _random_points(ora, 87, 100, "proj")
+    assert host(eng.is_torsion_free_batch(dev(prj), PROJECTIVE)).all()
+    jac = _random_points(ora, 87, 100, "jac")
+    assert host(eng.is_torsion_free_batch(dev(jac), JACOBIAN)).all()
+    hb = np.tile(np.array(kats["cofactor_bytes"], np.uint8), (len(pts), 1))
+    for in_form, p, out_form in ((AFFINE, pts, AFFINE), (AFFINE, pts, JACOBIAN), (PROJECTIVE, prj, PROJECTIVE), (JACOBIAN, jac, JACOBIAN)):
+        want, winf = ora.multiply_batch(p, in_form, hb[: len(p)], out_form, vartime=True)
+        got, inf = eng.clear_cofactor_batch(dev(p), in_form, out_form)
+        assert (host(got) == want).all() and (host(inf) == winf).all(), (in_form, out_form)
+    cleared, cinf = eng.clear_cofactor_batch(pts, AFFINE, AFFINE)
+    assert eng.is_torsion_free_batch(cleared, AFFINE).all()
+
+
 # ----------------------------------------- BASELINE-size property checks ----
 
 def test_full_size_configs_2_3_properties(eng, ora):
