@@ -157,4 +157,76 @@ inline std::vector<AffinePoint> multiply_batch(const Context& ctx, const std::ve
     return out;
 }
 
+// JacobianPoint::multiply(&self, by), src/curve/jacobian.rs:599-611 (constant time, Jacobian in / out)
+inline std::vector<JacobianPoint> multiply_batch(const Context& ctx, const std::vector<JacobianPoint>& p,
+                                                 const std::vector<Scalar>& by) {
+    if (p.size() != by.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<JacobianPoint> out(p.size());
+    ctx.check(cheetah_multiply_batch(ctx.get(), u64p(p.data()), CHEETAH_JACOBIAN, by.data()->bytes.data(), u64p(out.data()),
+                                     nullptr, p.size(), CHEETAH_JACOBIAN));
+    return out;
+}
+// JacobianPoint::multiply_vartime(&self, by), src/curve/jacobian.rs:619-649
+inline std::vector<JacobianPoint> multiply_vartime_batch(const Context& ctx, const std::vector<JacobianPoint>& p,
+                                                         const std::vector<Scalar>& by) {
+    if (p.size() != by.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<JacobianPoint> out(p.size());
+    ctx.check(cheetah_multiply_vartime_batch(ctx.get(), u64p(p.data()), CHEETAH_JACOBIAN, by.data()->bytes.data(),
+                                             u64p(out.data()), nullptr, p.size(), CHEETAH_JACOBIAN));
+    return out;
+}
+// &BASEPOINT_LOOKUP * &scalar, src/constants.rs:102-135 (Jacobian results)
+struct BasePointLookupT {
+    std::vector<JacobianPoint> multiply_batch(const Context& ctx, const std::vector<Scalar>& by) const {
+        std::vector<JacobianPoint> out(by.size());
+        ctx.check(cheetah_mul_by_generator_batch(ctx.get(), by.data()->bytes.data(), u64p(out.data()), nullptr, by.size(),
+                                                 CHEETAH_JACOBIAN));
+        return out;
+    }
+};
+static const BasePointLookupT BASEPOINT_LOOKUP{};
+
+// ProjectivePoint::multiply_many(points, scalars), src/curve/projective.rs:817-832, one call per group of m:
+// out[g] = sum_j scalars[g*m + j] * points[g*m + j]; m = 2 is multiply_double (:666-685).
+inline std::vector<ProjectivePoint> multiply_many_batch(const Context& ctx, const std::vector<ProjectivePoint>& points,
+                                                        const std::vector<Scalar>& scalars, int m, bool vartime = false) {
+    if (m < 1 || points.size() != scalars.size() || points.size() % (size_t)m) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<ProjectivePoint> out(points.size() / (size_t)m);
+    auto f = vartime ? cheetah_multiply_many_vartime_batch : cheetah_multiply_many_batch;
+    ctx.check(f(ctx.get(), u64p(points.data()), CHEETAH_PROJECTIVE, scalars.data()->bytes.data(), m, u64p(out.data()), nullptr,
+                out.size(), CHEETAH_PROJECTIVE));
+    return out;
+}
+// ProjectivePoint::multiply_double_with_basepoint_vartime, src/curve/projective.rs:756-809:
+// out[i] = by_self[i] * points[i] + by_basepoint[i] * G
+inline std::vector<ProjectivePoint> multiply_double_with_basepoint_vartime_batch(const Context& ctx,
+                                                                                 const std::vector<ProjectivePoint>& points,
+                                                                                 const std::vector<Scalar>& by_self,
+                                                                                 const std::vector<Scalar>& by_basepoint) {
+    if (points.size() != by_self.size() || points.size() != by_basepoint.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<Scalar> sc(2 * points.size());
+    for (size_t i = 0; i < points.size(); i++) {
+        sc[2 * i] = by_self[i];
+        sc[2 * i + 1] = by_basepoint[i];
+    }
+    std::vector<ProjectivePoint> out(points.size());
+    ctx.check(cheetah_multiply_double_with_basepoint_vartime_batch(ctx.get(), u64p(points.data()), CHEETAH_PROJECTIVE,
+                                                                   sc.data()->bytes.data(), u64p(out.data()), nullptr, out.size(),
+                                                                   CHEETAH_PROJECTIVE));
+    return out;
+}
+// ProjectivePoint::is_torsion_free, src/curve/projective.rs:885-893
+inline std::vector<uint8_t> is_torsion_free_batch(const Context& ctx, const std::vector<ProjectivePoint>& p) {
+    std::vector<uint8_t> flags(p.size());
+    ctx.check(cheetah_is_torsion_free_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, flags.data(), p.size()));
+    return flags;
+}
+// ProjectivePoint::clear_cofactor, src/curve/projective.rs:872-881
+inline std::vector<ProjectivePoint> clear_cofactor_batch(const Context& ctx, const std::vector<ProjectivePoint>& p) {
+    std::vector<ProjectivePoint> out(p.size());
+    ctx.check(cheetah_clear_cofactor_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, u64p(out.data()), nullptr, p.size(),
+                                           CHEETAH_PROJECTIVE));
+    return out;
+}
+
 }  // namespace cheetah
