@@ -66,12 +66,12 @@ int main() {
         std::memcpy(qs.bytes.data(), qb, 32);
         auto o = multiply_vartime_batch(ctx, {gp[0]}, {qs});
         EXPECT(o[0].z.c == zero.c);
-        // is_torsion_free(G) (src/curve/projective.rs:1462); 2*G + 2*G == 4*G through multiply_double;
+        // is_torsion_free(G) (src/curve/projective.rs:1462); 1*(2G) + 1*(2G) == 4*G through multiply_double;
         // 1*(2G) + 2*G == 4*G through the basepoint ladder; BASEPOINT_LOOKUP * 2 normalises to 2G
         EXPECT(is_torsion_free_batch(ctx, {gp[0]})[0] == 1);
-        auto dd = multiply_many_batch(ctx, {gp[0], gp[0]}, {two, two}, 2);
         Scalar one_s{};
         one_s.bytes[0] = 1;
+        auto dd = multiply_many_batch(ctx, {gp[0], gp[0]}, {one_s, one_s}, 2);
         auto db = multiply_double_with_basepoint_vartime_batch(ctx, {gp[0]}, {one_s}, {two});
         auto jl = BASEPOINT_LOOKUP.multiply_batch(ctx, {two});
         std::vector<ProjectivePoint> chk = {dd[0], db[0]};
