@@ -50,6 +50,12 @@ SIGNATURES = {
     "cheetah_clear_cofactor_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz, _i]),
     "cheetah_is_torsion_free_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_clear_cofactor_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz, _i]),
+    "cheetah_encode_uncompressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_encode_compressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_decode_uncompressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_encode_uncompressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_encode_compressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_decode_uncompressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "cheetah_read_table": (C.c_int32, [_vp, _i, _vp, _sz]),
     "cheetah_synth_fp6_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),
     "cheetah_synth_scalars_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),

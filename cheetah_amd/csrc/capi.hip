@@ -569,6 +569,8 @@ static int32_t fixed_scalar_dev(cheetah_ctx* ctx, const u64* pts, int in_form, c
             if (in_form == CHEETAH_PROJECTIVE) LAUNCH(Proj, 1, 3);
             else if (in_form == CHEETAH_JACOBIAN) LAUNCH(MJac, 2, 3);
             else LAUNCH(MJac, 0, 3);
+        } else if (out_form == 4) {  // flags[i] &= is_identity (affine input)
+            LAUNCH(MJac, 0, 4);
         } else if (proj) {
             if (in_form == CHEETAH_AFFINE) LAUNCH(Proj, 0, 1);
             else if (out_form == CHEETAH_AFFINE) LAUNCH(Proj, 1, 0);
@@ -671,6 +673,90 @@ extern "C" int32_t cheetah_clear_cofactor_batch(cheetah_ctx* ctx, const uint64_t
     if (int32_t rc = cheetah_clear_cofactor_batch_dev(ctx, dp.as<u64>(), in_form, dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
     D2H(ctx, out, dout.p, n * wo);
     if (inf) D2H(ctx, inf, dinf.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+
+// -------------------------------------------------------------- encodings -----
+
+static bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+template <int REC>
+static int32_t encode_dev(cheetah_ctx* ctx, const u64* xy, const u8* inf, u8* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!xy || !inf || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned16(xy) || !aligned4(out)) return fail(ctx, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
+    hipLaunchKernelGGL((k_encode<REC>), dim3((int)(tiles < cap ? tiles : cap)), dim3(BLOCK), 0, ctx->stream, xy, inf, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_encode_uncompressed_batch_dev(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out97, size_t n) {
+    return encode_dev<97>(ctx, xy, inf, out97, n);
+}
+extern "C" int32_t cheetah_encode_compressed_batch_dev(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out49, size_t n) {
+    return encode_dev<49>(ctx, xy, inf, out49, n);
+}
+extern "C" int32_t cheetah_decode_uncompressed_batch_dev(cheetah_ctx* ctx, const uint8_t* in97, uint64_t* xy, uint8_t* inf,
+                                                         uint8_t* is_some, size_t n, int checked) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!in97 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned16(xy) || !aligned4(in97)) return fail(ctx, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
+    int grid = (int)(tiles < cap ? tiles : cap);
+    if (checked) {
+        hipLaunchKernelGGL((k_decode_uncompressed<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, in97, xy, inf, is_some, n);
+        HIP_TRY(ctx, hipGetLastError());
+        if (int32_t rc = fixed_scalar_dev(ctx, xy, CHEETAH_AFFINE, ctx->fixed_scalars, nullptr, is_some, n, 4)) return rc;  // is_some &= is_torsion_free
+        hipLaunchKernelGGL(k_zero_rejected, dim3(grid), dim3(BLOCK), 0, ctx->stream, xy, inf, is_some, n);
+        HIP_TRY(ctx, hipGetLastError());
+        return CHEETAH_OK;
+    }
+    hipLaunchKernelGGL((k_decode_uncompressed<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, in97, xy, inf, is_some, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
+template <int REC>
+static int32_t encode_host(cheetah_ctx* ctx, const u64* xy, const u8* inf, u8* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!xy || !inf || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf dxy, dinf, dout;
+    HIP_TRY(ctx, dxy.alloc(n * 96));
+    HIP_TRY(ctx, dinf.alloc(n));
+    HIP_TRY(ctx, dout.alloc(n * REC));
+    H2D(ctx, dxy.p, xy, n * 96);
+    H2D(ctx, dinf.p, inf, n);
+    if (int32_t rc = encode_dev<REC>(ctx, dxy.as<u64>(), dinf.as<u8>(), dout.as<u8>(), n)) return rc;
+    D2H(ctx, out, dout.p, n * REC);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_encode_uncompressed_batch(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out97, size_t n) {
+    return encode_host<97>(ctx, xy, inf, out97, n);
+}
+extern "C" int32_t cheetah_encode_compressed_batch(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out49, size_t n) {
+    return encode_host<49>(ctx, xy, inf, out49, n);
+}
+extern "C" int32_t cheetah_decode_uncompressed_batch(cheetah_ctx* ctx, const uint8_t* in97, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
+                                                     size_t n, int checked) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!in97 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf din, dxy, dinf, dsome;
+    HIP_TRY(ctx, din.alloc(n * 97));
+    HIP_TRY(ctx, dxy.alloc(n * 96));
+    HIP_TRY(ctx, dinf.alloc(n));
+    HIP_TRY(ctx, dsome.alloc(n));
+    H2D(ctx, din.p, in97, n * 97);
+    if (int32_t rc = cheetah_decode_uncompressed_batch_dev(ctx, din.as<u8>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n, checked)) return rc;
+    D2H(ctx, xy, dxy.p, n * 96);
+    D2H(ctx, inf, dinf.p, n);
+    D2H(ctx, is_some, dsome.p, n);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CHEETAH_OK;
 }

@@ -58,11 +58,13 @@ CH_DEV void store_proj(u64* out, u8* inf, size_t i, const Proj& p) {
     if (inf) inf[i] = fp6_is_zero(p.z) ? 1 : 0;
 }
 // out_form 0: normalise (one Fp6 inversion per lane), 1: the projective representative as is
-// out_form 3: only the identity flag (is_identity() of the representative, z == 0)
+// out_form 3: only the identity flag (is_identity() of the representative, z == 0); 4: AND it into inf[i]
 template <int OUT_FORM>
 CH_DEV void emit_point(u64* out, u8* inf, size_t i, const Proj& p) {
     if (OUT_FORM == 3)
         inf[i] = fp6_is_zero(p.z) ? 1 : 0;
+    else if (OUT_FORM == 4)
+        inf[i] = (inf[i] && fp6_is_zero(p.z)) ? 1 : 0;
     else if (OUT_FORM == 0)
         store_affine(out, inf, i, affine_from_proj(p));
     else
@@ -79,6 +81,8 @@ CH_DEV void emit_point(u64* out, u8* inf, size_t i, const MJac& p) {
     j.z = p.z;
     if (OUT_FORM == 3)
         inf[i] = fp6_is_zero(p.z) ? 1 : 0;
+    else if (OUT_FORM == 4)  // flags[i] &= is_identity: the subgroup check of AffinePoint::from_uncompressed
+        inf[i] = (inf[i] && fp6_is_zero(p.z)) ? 1 : 0;
     else if (OUT_FORM == 0)
         store_affine(out, inf, i, affine_from_jac(j));
     else
@@ -775,6 +779,137 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_vartime(const Device
         }
         acc = Ladder<ACC>::add(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, g, acc);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Point encodings (src/curve/encoding.rs): 97-byte uncompressed and 49-byte
+// compressed forms.  Records are not a multiple of 4 bytes, so a workgroup's
+// 256 records are assembled in LDS and move to / from HBM as one contiguous,
+// dword-coalesced span (256 * 97 and 256 * 49 are multiples of 4).
+CH_DEV bool fp_lex_largest(u64 a) { return fp_canonical(a) >= 0x7fffffff80000001ull; }  // src/fp.rs:281-300
+// Fp6::lexicographically_largest, src/fp6.rs:398-424: the expression exactly as written there.
+CH_DEV bool fp6_lex_largest(const Fp6& a) {
+    bool r = fp_lex_largest(a.c[5]);
+#pragma unroll
+    for (int i = 4; i >= 0; i--) r = r || (fp_is_zero(a.c[i + 1]) && fp_lex_largest(a.c[i]));
+    return r;
+}
+CH_DEV void lds_put_fp6(u8* dst, const Fp6& a) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const u64 v = fp_canonical(a.c[i]);
+#pragma unroll
+        for (int b = 0; b < 8; b++) dst[8 * i + b] = (u8)(v >> (8 * b));
+    }
+}
+CH_DEV bool lds_get_fp6(const u8* src, Fp6& a) {  // Fp6::from_bytes: none unless every limb < p (src/fp6.rs:1154-1189)
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        u64 v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v |= (u64)src[8 * i + b] << (8 * b);
+        const bool some = v < FP_P;
+        ok = ok && some;
+        a.c[i] = some ? v : 0;
+    }
+    return ok;
+}
+
+// CompressedPoint::from_affine (REC = 49, src/curve/encoding.rs:55-77) and
+// UncompressedPoint::from_affine (REC = 97, :169-183).
+template <int REC>
+__global__ void __launch_bounds__(BLOCK) k_encode(const u64* __restrict__ xy, const u8* __restrict__ inf, u8* __restrict__ out,
+                                                  size_t n) {
+    __shared__ u32 s_buf[BLOCK * REC / 4];
+    u8* sb = reinterpret_cast<u8*>(s_buf);
+    const int t = threadIdx.x;
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t e0 = tile * BLOCK;
+        const size_t cnt = n - e0 < (size_t)BLOCK ? n - e0 : (size_t)BLOCK;
+        if ((size_t)t < cnt) {
+            const size_t e = e0 + t;
+            const bool is_inf = inf[e] != 0;
+            Fp6 x = load_fp6_vec(xy + 12 * e), y = load_fp6_vec(xy + 12 * e + 6);
+            u8* rec = sb + t * REC;
+            lds_put_fp6(rec, is_inf ? fp6_zero() : x);
+            if (REC == 97) {
+                lds_put_fp6(rec + 48, is_inf ? fp6_zero() : y);
+                rec[96] = is_inf ? 0x80 : 0;
+            } else {
+                rec[48] = (is_inf ? 0x80 : 0) | ((!is_inf && fp6_lex_largest(y)) ? 0x40 : 0);
+            }
+        }
+        __syncthreads();
+        const size_t bytes = cnt * REC;
+        u8* dst = out + e0 * REC;  // e0 * REC is a multiple of 4
+        for (size_t w = t; w < bytes / 4; w += BLOCK) reinterpret_cast<u32*>(dst)[w] = s_buf[w];
+        for (size_t b = (bytes / 4) * 4 + t; b < bytes; b += BLOCK) dst[b] = sb[b];
+        __syncthreads();
+    }
+}
+
+// UncompressedPoint::to_affine (src/curve/encoding.rs:187-226).  CHECKED adds the
+// on-curve test of AffinePoint::from_uncompressed (src/curve/affine.rs:289-292, :364-368);
+// its subgroup test runs afterwards as a fixed-scalar ladder that ANDs into is_some.
+// A rejected record comes out as (0, 0, inf = 0) with is_some = 0.
+template <int CHECKED>
+__global__ void __launch_bounds__(BLOCK) k_decode_uncompressed(const u8* __restrict__ in, u64* __restrict__ xy,
+                                                               u8* __restrict__ inf, u8* __restrict__ is_some, size_t n) {
+    constexpr int REC = 97;
+    __shared__ u32 s_buf[BLOCK * REC / 4];
+    u8* sb = reinterpret_cast<u8*>(s_buf);
+    const int t = threadIdx.x;
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t e0 = tile * BLOCK;
+        const size_t cnt = n - e0 < (size_t)BLOCK ? n - e0 : (size_t)BLOCK;
+        const size_t bytes = cnt * REC;
+        const u8* src = in + e0 * REC;
+        for (size_t w = t; w < bytes / 4; w += BLOCK) s_buf[w] = reinterpret_cast<const u32*>(src)[w];
+        for (size_t b = (bytes / 4) * 4 + t; b < bytes; b += BLOCK) sb[b] = src[b];
+        __syncthreads();
+        if ((size_t)t < cnt) {
+            const size_t e = e0 + t;
+            const u8* rec = sb + t * REC;
+            const bool flag = (rec[96] >> 7) & 1;
+            Affine p;
+            bool ok = lds_get_fp6(rec, p.x);
+            ok = lds_get_fp6(rec + 48, p.y) && ok;
+            ok = ok && (!flag || (fp6_is_zero(p.x) && fp6_is_zero(p.y)));
+            p.inf = flag;
+            if (flag) p = affine_identity();
+            if (CHECKED && ok && !p.inf) {  // y^2 - x (x^2 + 1) == B
+                Fp6 lhs = fp6_sub(fp6_square(p.y), fp6_mul(p.x, fp6_add(fp6_square(p.x), fp6_one())));
+                lhs = fp6_canonical(lhs);
+                ok = lhs.c[0] == 395 && lhs.c[1] == 1 && lhs.c[2] == 0 && lhs.c[3] == 0 && lhs.c[4] == 0 && lhs.c[5] == 0;
+            }
+            if (!ok) {
+                p.x = fp6_zero();
+                p.y = fp6_zero();
+                p.inf = false;
+            }
+            store_fp6_vec_canonical(xy + 12 * e, p.x);
+            store_fp6_vec_canonical(xy + 12 * e + 6, p.y);
+            inf[e] = p.inf ? 1 : 0;
+            is_some[e] = ok ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// A record rejected by the subgroup check leaves as (0, 0, inf = 0) like every other none.
+__global__ void __launch_bounds__(BLOCK) k_zero_rejected(u64* __restrict__ xy, u8* __restrict__ inf, const u8* __restrict__ is_some,
+                                                         size_t n) {
+    for (size_t w = (size_t)blockIdx.x * BLOCK + threadIdx.x; w < n * 12; w += (size_t)gridDim.x * BLOCK) {
+        const size_t e = w / 12;
+        if (!is_some[e]) {
+            xy[w] = 0;
+            if (w == e * 12) inf[e] = 0;
+        }
     }
 }
 

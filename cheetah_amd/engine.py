@@ -286,6 +286,48 @@ class Engine:
         self._check(self._lib.cheetah_clear_cofactor_batch(self._h, p.ctypes.data, in_form, out.ctypes.data, inf.ctypes.data, n, out_form))
         return out, inf
 
+    # -- point encodings ------------------------------------------------------------
+    def _encode(self, xy, inf, rec):
+        name = "cheetah_encode_uncompressed_batch" if rec == 97 else "cheetah_encode_compressed_batch"
+        if _is_torch(xy):
+            p = self._dev(xy, 8, 12)
+            n = p.shape[0]
+            out = self._empty((n, rec), torch.uint8)
+            self._use_torch_stream()
+            self._check(getattr(self._lib, name + "_dev")(self._h, p.data_ptr(), inf.data_ptr(), out.data_ptr(), n))
+            return out
+        p = self._np(xy, np.uint64, 12)
+        inf = np.ascontiguousarray(inf, np.uint8)
+        out = np.empty((len(p), rec), np.uint8)
+        self._check(getattr(self._lib, name)(self._h, p.ctypes.data, inf.ctypes.data, out.ctypes.data, len(p)))
+        return out
+
+    def to_uncompressed_batch(self, xy, inf):
+        """97-byte encodings (AffinePoint::to_uncompressed, src/curve/encoding.rs:169-183)."""
+        return self._encode(xy, inf, 97)
+
+    def to_compressed_batch(self, xy, inf):
+        """49-byte encodings (AffinePoint::to_compressed, src/curve/encoding.rs:55-77)."""
+        return self._encode(xy, inf, 49)
+
+    def from_uncompressed_batch(self, b, checked=True):
+        """(xy, inf, is_some): AffinePoint::from_uncompressed (checked: on the curve and torsion free,
+        src/curve/affine.rs:289-292) or from_uncompressed_unchecked (src/curve/encoding.rs:187-226)."""
+        if _is_torch(b):
+            b = self._dev(b, 1, 97)
+            n = b.shape[0]
+            xy, inf, some = self._empty((n, 12), torch.uint64), self._empty((n,), torch.uint8), self._empty((n,), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_decode_uncompressed_batch_dev(self._h, b.data_ptr(), xy.data_ptr(), inf.data_ptr(),
+                                                                        some.data_ptr(), n, int(checked)))
+            return xy, inf, some
+        b = self._np(b, np.uint8, 97)
+        n = len(b)
+        xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        self._check(self._lib.cheetah_decode_uncompressed_batch(self._h, b.ctypes.data, xy.ctypes.data, inf.ctypes.data,
+                                                                some.ctypes.data, n, int(checked)))
+        return xy, inf, some
+
     # -- tables / synthetic inputs / diagnostics -------------------------------------
     def read_table(self, which):
         n = {0: 256, 1: 3, 2: 128, 3: 64}[which]
@@ -447,6 +489,22 @@ class JacobianPoint:
 
 
 class AffinePoint:
+    @staticmethod
+    def to_uncompressed_batch(xy, inf, engine=None):
+        return (engine or default_engine()).to_uncompressed_batch(xy, inf)
+
+    @staticmethod
+    def to_compressed_batch(xy, inf, engine=None):
+        return (engine or default_engine()).to_compressed_batch(xy, inf)
+
+    @staticmethod
+    def from_uncompressed_batch(b, engine=None):
+        return (engine or default_engine()).from_uncompressed_batch(b, True)
+
+    @staticmethod
+    def from_uncompressed_unchecked_batch(b, engine=None):
+        return (engine or default_engine()).from_uncompressed_batch(b, False)
+
     @staticmethod
     def multiply_batch(points, scalars, engine=None):
         return (engine or default_engine()).multiply_batch(points, scalars, AFFINE, AFFINE)

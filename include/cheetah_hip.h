@@ -171,6 +171,27 @@ int32_t cheetah_is_torsion_free_batch_dev(cheetah_ctx *ctx, const uint64_t *pts,
 int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint64_t *out, uint8_t *inf,
                                          size_t n, int out_form);
 
+/* ---- point encodings (src/curve/encoding.rs) ------------------------------------
+ * cheetah_encode_uncompressed_batch  AffinePoint::to_uncompressed = UncompressedPoint::from_affine   :169-183
+ *                                    97 bytes: x | y canonical little-endian (zeros for the identity), flag byte bit 7 = infinity
+ * cheetah_encode_compressed_batch    AffinePoint::to_compressed = CompressedPoint::from_affine       :55-77
+ *                                    49 bytes: x, flag byte bit 7 = infinity, bit 6 = y.lexicographically_largest()
+ *                                    (src/fp6.rs:398-424, evaluated exactly as written there)
+ * cheetah_decode_uncompressed_batch  checked = 0: AffinePoint::from_uncompressed_unchecked = UncompressedPoint::to_affine  :187-226
+ *                                    checked = 1: AffinePoint::from_uncompressed: also is_on_curve and is_torsion_free
+ *                                                 (src/curve/affine.rs:289-292)
+ *                                    is_some[i] = 0 marks a CtOption::none; its point is written as (0, 0, inf = 0).
+ * Decompression of the 49-byte form needs Fp6::sqrt and is not built yet.
+ * `_dev`: xy 16-byte aligned, byte arrays 4-byte aligned. */
+int32_t cheetah_encode_uncompressed_batch(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out97, size_t n);
+int32_t cheetah_encode_compressed_batch(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out49, size_t n);
+int32_t cheetah_decode_uncompressed_batch(cheetah_ctx *ctx, const uint8_t *in97, uint64_t *xy, uint8_t *inf, uint8_t *is_some,
+                                          size_t n, int checked);
+int32_t cheetah_encode_uncompressed_batch_dev(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out97, size_t n);
+int32_t cheetah_encode_compressed_batch_dev(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out49, size_t n);
+int32_t cheetah_decode_uncompressed_batch_dev(cheetah_ctx *ctx, const uint8_t *in97, uint64_t *xy, uint8_t *inf,
+                                              uint8_t *is_some, size_t n, int checked);
+
 /* ---- precomputed tables (read back for inspection / tests) ----------------
  * which: 0 = BASEPOINT_TABLE (256 affine points, table-major, src/lookup.rs:136),
  *        1 = shift point S, -2^4 S, -2^256 S (3 affine points, src/constants.rs:43-90),

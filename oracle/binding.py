@@ -108,6 +108,12 @@ def lib():
         "ora_multiply_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_multiply_vartime_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_odd_multiples_basepoint": (C.POINTER(C.c_uint64), []),
+        "ora_fp6_lexicographically_largest": (C.c_int, [u64p]),
+        "ora_affine_to_compressed": (None, [u64p, C.c_uint8, u8p]),
+        "ora_affine_to_uncompressed": (None, [u64p, C.c_uint8, u8p]),
+        "ora_uncompressed_to_affine": (C.c_int, [u8p, C.c_int, u64p, u8p]),
+        "ora_encode_batch": (None, [u64p, u8p, u8p, C.c_size_t, C.c_int]),
+        "ora_decode_uncompressed_batch": (None, [u8p, C.c_int, u64p, u8p, u8p, C.c_size_t]),
         "ora_multiply_many_batch": (None, [u64p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_jac_batch_normalize_chunked": (None, [u64p, C.c_size_t, C.c_size_t, u64p, u8p]),
         "ora_proj_batch_normalize_chunked": (None, [u64p, C.c_size_t, C.c_size_t, u64p, u8p]),
@@ -211,6 +217,21 @@ def multiply_many_batch(pts, in_form, scalars, m, out_form=0, vartime=False, wit
     out, inf = _out_bufs(n, out_form)
     lib().ora_multiply_many_batch(p, in_form, s, m, int(vartime), int(with_basepoint), out, inf, n, out_form)
     return out, inf
+
+
+def encode_batch(xy, inf, compressed):
+    xy, inf = _u64(xy).reshape(-1, 12), _u8(inf)
+    out = np.empty((len(xy), 49 if compressed else 97), np.uint8)
+    lib().ora_encode_batch(xy, inf, out, len(xy), int(compressed))
+    return out
+
+
+def decode_uncompressed_batch(b, checked):
+    b = _u8(b).reshape(-1, 97)
+    n = len(b)
+    xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+    lib().ora_decode_uncompressed_batch(b, int(checked), xy, inf, some, n)
+    return xy, inf, some
 
 
 def batch_normalize(p, jacobian, chunk=0):

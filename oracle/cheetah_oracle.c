@@ -1424,6 +1424,96 @@ void ora_multiply_many_batch(const u64 *pts, int in_form, const uint8_t *scalars
     }
 }
 
+/* ------------------------------------------------------------ encodings ---- */
+
+/* Fp::lexicographically_largest, src/fp.rs:281-300 */
+static int fp_lex_largest(u64 a) { return fp_canonical(a) >= 0x7fffffff80000001ULL; }
+static int fp_is_zero(u64 a) { return fp_canonical(a) == 0; }
+/* Fp6::lexicographically_largest, src/fp6.rs:398-424 -- the expression exactly as written there
+ * (each term only looks at the coefficient just above it, not at all higher ones). */
+static int fp6_lex_largest(fp6 a) {
+    return fp_lex_largest(a.c[5]) | (fp_is_zero(a.c[5]) & fp_lex_largest(a.c[4])) | (fp_is_zero(a.c[4]) & fp_lex_largest(a.c[3])) |
+           (fp_is_zero(a.c[3]) & fp_lex_largest(a.c[2])) | (fp_is_zero(a.c[2]) & fp_lex_largest(a.c[1])) |
+           (fp_is_zero(a.c[1]) & fp_lex_largest(a.c[0]));
+}
+int ora_fp6_lexicographically_largest(const u64 *a) { return fp6_lex_largest(fp6_load(a)); }
+
+static void fp6_to_bytes(fp6 a, uint8_t *out) { /* src/fp6.rs:1139-1150, src/fp.rs:243-249 */
+    for (int i = 0; i < 6; i++) {
+        u64 v = fp_canonical(a.c[i]);
+        for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(v >> (8 * b));
+    }
+}
+static int fp6_from_bytes(const uint8_t *in, fp6 *out) { /* src/fp6.rs:1154-1189, src/fp.rs:253-268: none unless every limb < p */
+    int ok = 1;
+    for (int i = 0; i < 6; i++) {
+        u64 v = 0;
+        for (int b = 0; b < 8; b++) v |= (u64)in[8 * i + b] << (8 * b);
+        int some = v < P_MOD;
+        ok &= some;
+        out->c[i] = some ? v : 0; /* unwrap_or(Fp::zero()) */
+    }
+    return ok;
+}
+/* CompressedPoint::from_affine, src/curve/encoding.rs:55-77 */
+void ora_affine_to_compressed(const u64 *xy, uint8_t inf, uint8_t *out49) {
+    affine p = affine_load(xy, inf);
+    memset(out49, 0, 49);
+    fp6_to_bytes(p.inf ? FP6_ZERO : p.x, out49);
+    if (p.inf) out49[48] |= 1u << 7;
+    if (!p.inf && fp6_lex_largest(p.y)) out49[48] |= 1u << 6;
+}
+/* UncompressedPoint::from_affine, src/curve/encoding.rs:169-183 */
+void ora_affine_to_uncompressed(const u64 *xy, uint8_t inf, uint8_t *out97) {
+    affine p = affine_load(xy, inf);
+    memset(out97, 0, 97);
+    fp6_to_bytes(p.inf ? FP6_ZERO : p.x, out97);
+    fp6_to_bytes(p.inf ? FP6_ZERO : p.y, out97 + 48);
+    if (p.inf) out97[96] |= 1u << 7;
+}
+static int affine_is_on_curve(affine p) { /* src/curve/affine.rs:364-368 */
+    fp6 lhs = fp6_sub(fp6_square(p.y), fp6_mul(p.x, fp6_add(fp6_square(p.x), FP6_ONE)));
+    return fp6_eq(lhs, CURVE_B) | (p.inf != 0);
+}
+/* UncompressedPoint::to_affine (checked = 0, src/curve/encoding.rs:187-226) and
+ * AffinePoint::from_uncompressed (checked = 1: also on the curve and torsion free,
+ * src/curve/affine.rs:289-292).  Returns is_some; on none the output is (0, 0, inf = 0). */
+int ora_uncompressed_to_affine(const uint8_t *in97, int checked, u64 *out_xy, uint8_t *out_inf) {
+    int inf_flag = (in97[96] >> 7) & 1;
+    fp6 x, y;
+    int ok = fp6_from_bytes(in97, &x) & fp6_from_bytes(in97 + 48, &y);
+    affine p = {x, y, (uint8_t)inf_flag};
+    if (inf_flag) p = affine_identity();
+    ok &= (!inf_flag) | (inf_flag & fp6_is_zero(x) & fp6_is_zero(y));
+    if (ok && checked) {
+        ok &= affine_is_on_curve(p);
+        if (ok) { /* is_torsion_free: JacobianPoint::multiply_vartime(q).is_identity(), src/curve/affine.rs:463-467 */
+            static const uint8_t QB[32] = {207, 172, 212, 174, 62, 98, 67, 212, 34, 119, 21, 48, 35, 167, 122, 50,
+                                           181, 55, 10, 153, 15, 191, 63, 86, 208, 34, 63, 59, 155, 89, 242, 122};
+            proj r = jac_multiply_vartime(proj_from_affine(p), QB);
+            ok &= fp6_is_zero(r.z);
+        }
+    }
+    if (!ok) {
+        affine z = {FP6_ZERO, FP6_ZERO, 0};
+        p = z;
+    }
+    affine_store(out_xy, out_inf, p);
+    return ok;
+}
+void ora_encode_batch(const u64 *xy, const uint8_t *inf, uint8_t *out, size_t n, int compressed) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        if (compressed) ora_affine_to_compressed(xy + 12 * i, inf[i], out + 49 * i);
+        else ora_affine_to_uncompressed(xy + 12 * i, inf[i], out + 97 * i);
+    }
+}
+void ora_decode_uncompressed_batch(const uint8_t *in, int checked, u64 *xy, uint8_t *inf, uint8_t *is_some, size_t n) {
+    ora_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) is_some[i] = (uint8_t)ora_uncompressed_to_affine(in + 97 * i, checked, xy + 12 * i, inf + i);
+}
+
 static void batch_normalize_chunked(const u64 *p, size_t n, size_t chunk, u64 *xy, uint8_t *inf, int jac) {
     if (chunk == 0) chunk = n ? n : 1;
     size_t nchunks = (n + chunk - 1) / chunk;

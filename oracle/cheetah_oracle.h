@@ -135,6 +135,13 @@ void ora_multiply_vartime_batch(const uint64_t *pts, int in_form, const uint8_t 
  * (src/curve/projective.rs:693-809, :840-869, src/curve/jacobian.rs:681-858).  m <= 64. */
 void ora_multiply_many_batch(const uint64_t *pts, int in_form, const uint8_t *scalars, int m, int vartime, int with_basepoint,
                              uint64_t *out, uint8_t *out_inf, size_t n_groups, int out_form);
+/* ---- point encodings (src/curve/encoding.rs) ---- */
+int ora_fp6_lexicographically_largest(const uint64_t *a);                                   /* src/fp6.rs:398-424 */
+void ora_affine_to_compressed(const uint64_t *xy, uint8_t inf, uint8_t *out49);             /* encoding.rs:55-77 */
+void ora_affine_to_uncompressed(const uint64_t *xy, uint8_t inf, uint8_t *out97);           /* encoding.rs:169-183 */
+int ora_uncompressed_to_affine(const uint8_t *in97, int checked, uint64_t *out_xy, uint8_t *out_inf); /* encoding.rs:187-226, affine.rs:289-292 */
+void ora_encode_batch(const uint64_t *xy, const uint8_t *inf, uint8_t *out, size_t n, int compressed);
+void ora_decode_uncompressed_batch(const uint8_t *in, int checked, uint64_t *xy, uint8_t *inf, uint8_t *is_some, size_t n);
 /* chunked: the reference call is one sequential chain per call; the batch driver
  * issues one reference-shaped call per `chunk` points per thread. */
 void ora_jac_batch_normalize_chunked(const uint64_t *p, size_t n, size_t chunk, uint64_t *out_xy, uint8_t *out_inf);

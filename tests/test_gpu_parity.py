@@ -549,6 +549,44 @@ def test_is_torsion_free_and_clear_cofactor(eng, ora, kats):
     assert eng.is_torsion_free_batch(cleared, AFFINE).all()
 
 
+
+# ---------------------------------------------------------------- encodings ----
+
+@pytest.mark.parametrize("n", [1, 255, 256, 1031])
+def test_encodings_vs_oracle(eng, ora, kats, n):
+    """to_uncompressed / to_compressed / from_uncompressed(_unchecked) (src/curve/encoding.rs), ragged sizes,
+    identities, the reference's identity byte strings, and every rejection case."""
+    xy, inf = ora.mul_by_generator_batch(synth.scalars(23, n), 0)
+    xy, inf = xy.copy(), inf.copy()
+    if n > 5:
+        xy[3] = [0] * 6 + [1] + [0] * 5
+        inf[3] = 1
+        xy[4, 0] = np.uint64(int(xy[4, 0]) + P) if int(xy[4, 0]) + P < 2**64 else xy[4, 0]   # non-canonical limb in
+    for compressed in (False, True):
+        want = ora.encode_batch(xy, inf, compressed)
+        f = eng.to_compressed_batch if compressed else eng.to_uncompressed_batch
+        assert (host(f(dev(xy), dev(inf))) == want).all()
+        assert (f(xy, inf) == want).all()
+    if n > 5:
+        assert list(eng.to_compressed_batch(xy, inf)[3]) == kats["identity_encodings"]["compressed"]
+        assert list(eng.to_uncompressed_batch(xy, inf)[3]) == kats["identity_encodings"]["uncompressed"]
+    enc = ora.encode_batch(xy, inf, False)
+    if n > 5:
+        ns = np.array([kats["non_subgroup_point"]["x"] + kats["non_subgroup_point"]["y"]], np.uint64)
+        enc[0, 0:8] = 0xFF                                        # non-canonical limb: none
+        enc[1, :] = 0                                             # (0, 0) without the flag: unchecked accepts, checked rejects
+        enc[2, 96] = 0x80                                         # flag with non-zero coordinates: none
+        enc[5] = ora.encode_batch(ns, np.zeros(1, np.uint8), False)[0]   # on the curve, outside the subgroup
+    for checked in (False, True):
+        wxy, winf, wsome = ora.decode_uncompressed_batch(enc, checked)
+        gxy, ginf, gsome = eng.from_uncompressed_batch(dev(enc), checked)
+        assert (host(gxy) == wxy).all() and (host(ginf) == winf).all() and (host(gsome) == wsome).all(), checked
+        hxy, hinf, hsome = eng.from_uncompressed_batch(enc, checked)
+        assert (hxy == wxy).all() and (hinf == winf).all() and (hsome == wsome).all()
+    if n > 5:
+        assert list(wsome[:6]) == [0, 0, 0, 1, 1, 0]
+
+
 # ----------------------------------------- BASELINE-size property checks ----
 
 def test_full_size_configs_2_3_properties(eng, ora):
