@@ -27,6 +27,8 @@ SIGNATURES = {
     "cheetah_fp6_mul_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_fp6_square_batch": (C.c_int32, [_vp, _vp, _vp, _sz]),
     "cheetah_fp6_invert_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_fp6_sqrt_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_fp6_sqrt_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_fp6_mul_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_fp6_square_batch_dev": (C.c_int32, [_vp, _vp, _vp, _sz]),
     "cheetah_fp6_invert_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
@@ -53,6 +55,10 @@ SIGNATURES = {
     "cheetah_encode_uncompressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_encode_compressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_decode_uncompressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_decode_compressed_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_decode_compressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_affine_from_x_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "cheetah_affine_from_x_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz]),
     "cheetah_encode_uncompressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_encode_compressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_decode_uncompressed_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),

@@ -223,6 +223,9 @@ extern "C" int32_t cheetah_fp6_square_batch_dev(cheetah_ctx* ctx, const uint64_t
 extern "C" int32_t cheetah_fp6_invert_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
     return fp6_elementwise_dev<EW_INVERT>(ctx, a, nullptr, out, is_some, n);
 }
+extern "C" int32_t cheetah_fp6_sqrt_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    return fp6_elementwise_dev<EW_SQRT>(ctx, a, nullptr, out, is_some, n);
+}
 
 // ------------------------------------------------------ batch_normalize -----
 
@@ -392,7 +395,8 @@ extern "C" int32_t cheetah_fp6_square_batch(cheetah_ctx* ctx, const uint64_t* a,
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CHEETAH_OK;
 }
-extern "C" int32_t cheetah_fp6_invert_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+template <int OP>
+static int32_t fp6_option_host(cheetah_ctx* ctx, const u64* a, u64* out, u8* is_some, size_t n) {
     CHECK_CTX(ctx);
     if (n == 0) return CHEETAH_OK;
     if (!a || !out || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
@@ -401,11 +405,17 @@ extern "C" int32_t cheetah_fp6_invert_batch(cheetah_ctx* ctx, const uint64_t* a,
     HIP_TRY(ctx, dout.alloc(n * 48));
     HIP_TRY(ctx, dsome.alloc(n));
     H2D(ctx, da.p, a, n * 48);
-    if (int32_t rc = cheetah_fp6_invert_batch_dev(ctx, da.as<u64>(), dout.as<u64>(), dsome.as<u8>(), n)) return rc;
+    if (int32_t rc = fp6_elementwise_dev<OP>(ctx, da.as<u64>(), nullptr, dout.as<u64>(), dsome.as<u8>(), n)) return rc;
     D2H(ctx, out, dout.p, n * 48);
     D2H(ctx, is_some, dsome.p, n);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_fp6_invert_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    return fp6_option_host<EW_INVERT>(ctx, a, out, is_some, n);
+}
+extern "C" int32_t cheetah_fp6_sqrt_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    return fp6_option_host<EW_SQRT>(ctx, a, out, is_some, n);
 }
 
 template <int JAC>
@@ -720,6 +730,35 @@ extern "C" int32_t cheetah_decode_uncompressed_batch_dev(cheetah_ctx* ctx, const
     return CHEETAH_OK;
 }
 
+extern "C" int32_t cheetah_decode_compressed_batch_dev(cheetah_ctx* ctx, const uint8_t* in49, uint64_t* xy, uint8_t* inf,
+                                                       uint8_t* is_some, size_t n, int checked) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!in49 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned16(xy) || !aligned4(in49)) return fail(ctx, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
+    int grid = (int)(tiles < cap ? tiles : cap);
+    hipLaunchKernelGGL(k_decode_compressed, dim3(grid), dim3(BLOCK), 0, ctx->stream, in49, xy, inf, is_some, n);
+    HIP_TRY(ctx, hipGetLastError());
+    if (checked) {
+        if (int32_t rc = fixed_scalar_dev(ctx, xy, CHEETAH_AFFINE, ctx->fixed_scalars, nullptr, is_some, n, 4)) return rc;  // is_some &= is_torsion_free
+        hipLaunchKernelGGL(k_zero_rejected, dim3(grid), dim3(BLOCK), 0, ctx->stream, xy, inf, is_some, n);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_affine_from_x_batch_dev(cheetah_ctx* ctx, const uint64_t* x, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
+                                                   size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!x || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (!aligned16(x) || !aligned16(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
+    hipLaunchKernelGGL(k_affine_from_x, dim3((int)(tiles < cap ? tiles : cap)), dim3(BLOCK), 0, ctx->stream, x, xy, inf, is_some, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
 template <int REC>
 static int32_t encode_host(cheetah_ctx* ctx, const u64* xy, const u8* inf, u8* out, size_t n) {
     CHECK_CTX(ctx);
@@ -754,6 +793,42 @@ extern "C" int32_t cheetah_decode_uncompressed_batch(cheetah_ctx* ctx, const uin
     HIP_TRY(ctx, dsome.alloc(n));
     H2D(ctx, din.p, in97, n * 97);
     if (int32_t rc = cheetah_decode_uncompressed_batch_dev(ctx, din.as<u8>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n, checked)) return rc;
+    D2H(ctx, xy, dxy.p, n * 96);
+    D2H(ctx, inf, dinf.p, n);
+    D2H(ctx, is_some, dsome.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_decode_compressed_batch(cheetah_ctx* ctx, const uint8_t* in49, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
+                                                   size_t n, int checked) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!in49 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf din, dxy, dinf, dsome;
+    HIP_TRY(ctx, din.alloc(n * 49));
+    HIP_TRY(ctx, dxy.alloc(n * 96));
+    HIP_TRY(ctx, dinf.alloc(n));
+    HIP_TRY(ctx, dsome.alloc(n));
+    H2D(ctx, din.p, in49, n * 49);
+    if (int32_t rc = cheetah_decode_compressed_batch_dev(ctx, din.as<u8>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n, checked)) return rc;
+    D2H(ctx, xy, dxy.p, n * 96);
+    D2H(ctx, inf, dinf.p, n);
+    D2H(ctx, is_some, dsome.p, n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+extern "C" int32_t cheetah_affine_from_x_batch(cheetah_ctx* ctx, const uint64_t* x, uint64_t* xy, uint8_t* inf, uint8_t* is_some, size_t n) {
+    CHECK_CTX(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!x || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    DevBuf dx, dxy, dinf, dsome;
+    HIP_TRY(ctx, dx.alloc(n * 48));
+    HIP_TRY(ctx, dxy.alloc(n * 96));
+    HIP_TRY(ctx, dinf.alloc(n));
+    HIP_TRY(ctx, dsome.alloc(n));
+    H2D(ctx, dx.p, x, n * 48);
+    if (int32_t rc = cheetah_affine_from_x_batch_dev(ctx, dx.as<u64>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n)) return rc;
     D2H(ctx, xy, dxy.p, n * 96);
     D2H(ctx, inf, dinf.p, n);
     D2H(ctx, is_some, dsome.p, n);

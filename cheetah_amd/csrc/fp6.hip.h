@@ -221,6 +221,152 @@ CH_DEV Fp6 fp6_invert(const Fp6& a, bool* is_some) {
     return fp6_mul_by_fp(t5, fp_invert(n));
 }
 
+
+// ---------------------------------------------------------------------------
+// Fp3 = Fp[X]/(X^3 - 7), the subfield embedded as (c0, c2, c4) (src/fp3.rs:41-48,
+// :112-120), and the square roots built on it.  Same values as the reference's
+// Karatsuba forms; here the nine-term convolution in Acc3 accumulators.
+struct Fp3 {
+    u64 a[3];
+};
+CH_DEV Fp3 fp3_one() {
+    Fp3 r;
+    r.a[0] = 1;
+    r.a[1] = 0;
+    r.a[2] = 0;
+    return r;
+}
+CH_DEV Fp3 fp3_zero() {
+    Fp3 r;
+    r.a[0] = r.a[1] = r.a[2] = 0;
+    return r;
+}
+// src/fp3.rs:169-211 (mul), :215-252 (square)
+__device__ __noinline__ void fp3_mul_fn(const u64 x0, const u64 x1, const u64 x2, const u64 y0, const u64 y1, const u64 y2, u64* out) {
+    const u64 y1s = fp_mul_small(y1, 7u), y2s = fp_mul_small(y2, 7u);
+    Acc3 acc;
+    acc.init(x0, y0);
+    acc.mac(x1, y2s);
+    acc.mac(x2, y1s);
+    out[0] = acc.reduce();
+    acc.init(x0, y1);
+    acc.mac(x1, y0);
+    acc.mac(x2, y2s);
+    out[1] = acc.reduce();
+    acc.init(x0, y2);
+    acc.mac(x1, y1);
+    acc.mac(x2, y0);
+    out[2] = acc.reduce();
+}
+CH_DEV Fp3 fp3_mul(const Fp3& x, const Fp3& y) {
+    Fp3 r;
+    fp3_mul_fn(x.a[0], x.a[1], x.a[2], y.a[0], y.a[1], y.a[2], r.a);
+    return r;
+}
+CH_DEV Fp3 fp3_square(const Fp3& x) { return fp3_mul(x, x); }
+CH_DEV bool fp3_eq(const Fp3& x, const Fp3& y) {
+    return fp_canonical(x.a[0]) == fp_canonical(y.a[0]) && fp_canonical(x.a[1]) == fp_canonical(y.a[1]) &&
+           fp_canonical(x.a[2]) == fp_canonical(y.a[2]);
+}
+CH_DEV Fp3 fp3_select(const Fp3& a, const Fp3& b, bool choice) {  // choice ? b : a
+    Fp3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.a[i] = choice ? b.a[i] : a.a[i];
+    return r;
+}
+// Fp3::sqrt: Tonelli-Shanks for 2-adicity 32 in its constant-time form (src/fp3.rs:255-282).
+// Returns s and *is_some = (s^2 == x).
+CH_DEV Fp3 fp3_sqrt(const Fp3& x, bool* is_some) {
+    // y = x^((t - 1) / 2), exponent 0x7ffffffe80000002fffffffc80000002fffffffe (src/fp3.rs:260-262)
+    const u64 E[3] = {0x80000002fffffffeull, 0x80000002fffffffcull, 0x000000007ffffffeull};
+    Fp3 y = fp3_one();
+    for (int w = 2; w >= 0; w--) {
+        for (int i = 63; i >= 0; i--) {
+            y = fp3_square(y);
+            if ((E[w] >> i) & 1) y = fp3_mul(y, x);  // fixed exponent: uniform branch
+        }
+    }
+    Fp3 s = fp3_mul(x, y), t = fp3_mul(s, y);
+    Fp3 z;
+    z.a[0] = 2800184025912956819ull;  // TWO_ADIC_ROOT_OF_UNITY_P3, src/fp3.rs:33-37
+    z.a[1] = 0;
+    z.a[2] = 0;
+    for (int k = 32; k >= 2; k--) {
+        Fp3 b = t;
+        for (int i = 0; i < k - 2; i++) b = fp3_square(b);
+        const bool is_one = fp3_eq(b, fp3_one());
+        const Fp3 new_s = fp3_mul(s, z);
+        s = fp3_select(new_s, s, is_one);
+        z = fp3_square(z);
+        const Fp3 new_t = fp3_mul(t, z);
+        t = fp3_select(new_t, t, is_one);
+    }
+    *is_some = fp3_eq(fp3_square(s), x);
+    return s;
+}
+
+// (A0 + A1 Y) * f and (A0 + A1 Y) * (f Y) with Y^2 = X, A0 = (c0, c2, c4), A1 = (c1, c3, c5)
+// (Fp6::mul_by_low_fp3 / mul_by_high_fp3, src/fp6.rs:469-647).
+CH_DEV Fp6 fp6_mul_by_low_fp3(const Fp6& s, const Fp3& f) {
+    Fp3 a0, a1;
+    a0.a[0] = s.c[0]; a0.a[1] = s.c[2]; a0.a[2] = s.c[4];
+    a1.a[0] = s.c[1]; a1.a[1] = s.c[3]; a1.a[2] = s.c[5];
+    const Fp3 lo = fp3_mul(a0, f), hi = fp3_mul(a1, f);
+    Fp6 r;
+    r.c[0] = lo.a[0]; r.c[2] = lo.a[1]; r.c[4] = lo.a[2];
+    r.c[1] = hi.a[0]; r.c[3] = hi.a[1]; r.c[5] = hi.a[2];
+    return r;
+}
+CH_DEV Fp6 fp6_mul_by_high_fp3(const Fp6& s, const Fp3& f) {
+    Fp3 a0, a1;
+    a0.a[0] = s.c[0]; a0.a[1] = s.c[2]; a0.a[2] = s.c[4];
+    a1.a[0] = s.c[1]; a1.a[1] = s.c[3]; a1.a[2] = s.c[5];
+    const Fp3 d1 = fp3_mul(a1, f), d2 = fp3_mul(a0, f);
+    Fp6 r;  // low half = X * (A1 f) = (7 d1[2], d1[0], d1[1]); high half = A0 f
+    r.c[0] = fp_mul_small(d1.a[2], 7u); r.c[2] = d1.a[0]; r.c[4] = d1.a[1];
+    r.c[1] = d2.a[0]; r.c[3] = d2.a[1]; r.c[5] = d2.a[2];
+    return r;
+}
+CH_DEV bool fp6_eq(const Fp6& a, const Fp6& b) {
+    bool e = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) e = e && fp_canonical(a.c[i]) == fp_canonical(b.c[i]);
+    return e;
+}
+// Fp6::sqrt, Algorithm 10 of eprint 2012/685 as in src/fp6.rs:922-964.
+CH_DEV Fp6 fp6_sqrt(const Fp6& self, bool* is_some) {
+    Fp3 E, F;
+    E.a[0] = 17474221990273267221ull; E.a[1] = 11073203528037158631ull; E.a[2] = 1587630551273719300ull;
+    F.a[0] = 16; F.a[1] = 18446744069414584320ull; F.a[2] = 0;
+    Fp6 b = fp6_mul(self, fp6_frobenius(self));
+    b = fp6_mul(b, fp6_frobenius_double(self));
+    {   // b^0x3fffffffc0000000 (src/fp6.rs:947): 32 one bits, then 30 squarings
+        const Fp6 base = b;
+        Fp6 r = base;
+        for (int i = 0; i < 31; i++) r = fp6_mul(fp6_square(r), base);
+        for (int i = 0; i < 30; i++) r = fp6_square(r);
+        b = r;
+    }
+    const Fp6 b2 = fp6_square(b);
+    const Fp6 b_pow_p3 = fp6_frobenius_triple(b);
+    const Fp6 check = fp6_mul(b_pow_p3, b);
+    const Fp6 s = fp6_mul(b2, self);
+    const Fp6 sf = fp6_mul_by_low_fp3(s, F);
+    Fp3 s3, sf3;
+    s3.a[0] = s.c[0]; s3.a[1] = s.c[2]; s3.a[2] = s.c[4];
+    sf3.a[0] = sf.c[0]; sf3.a[1] = sf.c[2]; sf3.a[2] = sf.c[4];
+    const bool is_one = fp6_eq(check, fp6_one());
+    // the reference takes both Fp3 roots and selects; only the selected one is computed here (same value)
+    bool some3;
+    Fp3 x0 = fp3_sqrt(is_one ? s3 : sf3, &some3);
+    if (!some3) x0 = fp3_zero();  // unwrap_or(Fp3::zero())
+    Fp6 x = fp6_mul_by_low_fp3(b_pow_p3, x0);
+    const Fp6 xe = fp6_mul_by_high_fp3(x, E);
+    x = fp6_select(xe, x, is_one);
+    *is_some = fp6_eq(fp6_square(x), self);
+    return x;
+}
+
 // a * (3u + 1185) = a * 3B.                          (src/curve/mod.rs:54-106)
 CH_DEV Fp6 fp6_mul_by_3b(const Fp6& a) {
     Fp6 r;

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
 // issue back to back, so the line is fetched from HBM once and served from the
 // CU's L1 after that; no LDS staging and no barriers, which leaves the waves
 // free to overlap one element's loads with another's arithmetic.
-enum { EW_MUL = 0, EW_SQUARE = 1, EW_INVERT = 2 };
+enum { EW_MUL = 0, EW_SQUARE = 1, EW_INVERT = 2, EW_SQRT = 3 };
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
@@ -190,10 +190,14 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
             r = fp6_mul(x, load_fp6_vec(b + 6 * i));
         else if (OP == EW_SQUARE)
             r = fp6_square(x);
-        else
+        else if (OP == EW_INVERT)
             r = fp6_invert(x, &some);
+        else {  // CtOption::none leaves as 0 with is_some = 0
+            r = fp6_sqrt(x, &some);
+            r = fp6_select(fp6_zero(), r, some);
+        }
         store_fp6_vec_canonical(out + 6 * i, r);
-        if (OP == EW_INVERT && is_some) is_some[i] = some ? 1 : 0;
+        if ((OP == EW_INVERT || OP == EW_SQRT) && is_some) is_some[i] = some ? 1 : 0;
     }
 }
 
@@ -898,6 +902,89 @@ __global__ void __launch_bounds__(BLOCK) k_decode_uncompressed(const u8* __restr
             is_some[e] = ok ? 1 : 0;
         }
         __syncthreads();
+    }
+}
+
+// x^3 + x + B, B = u + 395 (src/curve/mod.rs:42-49): the right-hand side whose root is y.
+CH_DEV Fp6 curve_rhs(const Fp6& x) {
+    Fp6 r = fp6_add(fp6_mul(fp6_square(x), x), x);
+    r.c[0] = fp_add(r.c[0], 395ull);
+    r.c[1] = fp_add(r.c[1], 1ull);
+    return r;
+}
+
+// CompressedPoint::to_affine = AffinePoint::from_compressed_unchecked (src/curve/encoding.rs:82-129):
+// x from its 48 bytes, y = sqrt(x^3 + x + B) (Fp6::sqrt, src/fp6.rs:922-964), negated when its
+// lexicographic rank disagrees with flag bit 6.  The subgroup test of AffinePoint::from_compressed
+// (src/curve/affine.rs:303-309) runs afterwards as a fixed-scalar ladder that ANDs into is_some.
+// A rejected record comes out as (0, 0, inf = 0) with is_some = 0.
+__global__ void __launch_bounds__(BLOCK) k_decode_compressed(const u8* __restrict__ in, u64* __restrict__ xy, u8* __restrict__ inf,
+                                                             u8* __restrict__ is_some, size_t n) {
+    constexpr int REC = 49;
+    __shared__ u32 s_buf[BLOCK * REC / 4];
+    u8* sb = reinterpret_cast<u8*>(s_buf);
+    const int t = threadIdx.x;
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t e0 = tile * BLOCK;
+        const size_t cnt = n - e0 < (size_t)BLOCK ? n - e0 : (size_t)BLOCK;
+        const size_t bytes = cnt * REC;
+        const u8* src = in + e0 * REC;
+        for (size_t w = t; w < bytes / 4; w += BLOCK) s_buf[w] = reinterpret_cast<const u32*>(src)[w];
+        for (size_t b = (bytes / 4) * 4 + t; b < bytes; b += BLOCK) sb[b] = src[b];
+        __syncthreads();
+        if ((size_t)t < cnt) {
+            const size_t e = e0 + t;
+            const u8* rec = sb + t * REC;
+            const bool inf_flag = (rec[48] >> 7) & 1, sort_flag = (rec[48] >> 6) & 1;
+            Affine p = affine_identity();
+            bool ok = lds_get_fp6(rec, p.x);
+            if (ok && !(inf_flag && !sort_flag && fp6_is_zero(p.x))) {
+                Fp6 y = fp6_sqrt(curve_rhs(p.x), &ok);
+                if (fp6_lex_largest(y) != sort_flag) y = fp6_neg(y);
+                p.y = y;
+                p.inf = inf_flag;
+                ok = ok && !inf_flag;
+            }
+            if (!ok) {
+                p.x = fp6_zero();
+                p.y = fp6_zero();
+                p.inf = false;
+            }
+            store_fp6_vec_canonical(xy + 12 * e, p.x);
+            store_fp6_vec_canonical(xy + 12 * e + 6, p.y);
+            inf[e] = p.inf ? 1 : 0;
+            is_some[e] = ok ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// AffinePoint::from_x (src/curve/affine.rs:326-343): x = 0 is the identity, otherwise the point
+// with the lexicographically largest y over x; none (0, 0, inf = 0, is_some = 0) when
+// x^3 + x + B is not a square.
+__global__ void __launch_bounds__(BLOCK) k_affine_from_x(const u64* __restrict__ x, u64* __restrict__ xy, u8* __restrict__ inf,
+                                                         u8* __restrict__ is_some, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Affine p;
+        p.x = load_fp6_vec(x + 6 * i);
+        bool ok = true;
+        if (fp6_is_zero(p.x)) {
+            p = affine_identity();
+        } else {
+            Fp6 y = fp6_sqrt(curve_rhs(p.x), &ok);
+            if (!fp6_lex_largest(y)) y = fp6_neg(y);
+            p.y = y;
+            p.inf = false;
+            if (!ok) {
+                p.x = fp6_zero();
+                p.y = fp6_zero();
+            }
+        }
+        store_fp6_vec_canonical(xy + 12 * i, p.x);
+        store_fp6_vec_canonical(xy + 12 * i + 6, p.y);
+        inf[i] = p.inf ? 1 : 0;
+        is_some[i] = ok ? 1 : 0;
     }
 }
 

@@ -114,21 +114,29 @@ class Engine:
         self._check(self._lib.cheetah_fp6_square_batch(self._h, a.ctypes.data, out.ctypes.data, len(a)))
         return out
 
-    def fp6_invert_batch(self, a):
-        """(out, is_some): out[i] = a[i]^-1, is_some[i] = 0 and out[i] = 0 for zero
-        (Fp6::invert -> CtOption, src/fp6.rs:1035-1049)"""
+    def _fp6_option(self, name, a):
         if _is_torch(a):
             a = self._dev(a, 8, 6)
             out = self._empty(a.shape, torch.uint64)
             some = self._empty((a.shape[0],), torch.uint8)
             self._use_torch_stream()
-            self._check(self._lib.cheetah_fp6_invert_batch_dev(self._h, a.data_ptr(), out.data_ptr(), some.data_ptr(), a.shape[0]))
+            self._check(getattr(self._lib, name + "_dev")(self._h, a.data_ptr(), out.data_ptr(), some.data_ptr(), a.shape[0]))
             return out, some
         a = self._np(a, np.uint64, 6)
         out = np.empty_like(a)
         some = np.empty(len(a), np.uint8)
-        self._check(self._lib.cheetah_fp6_invert_batch(self._h, a.ctypes.data, out.ctypes.data, some.ctypes.data, len(a)))
+        self._check(getattr(self._lib, name)(self._h, a.ctypes.data, out.ctypes.data, some.ctypes.data, len(a)))
         return out, some
+
+    def fp6_invert_batch(self, a):
+        """(out, is_some): out[i] = a[i]^-1, is_some[i] = 0 and out[i] = 0 for zero
+        (Fp6::invert -> CtOption, src/fp6.rs:1035-1049)"""
+        return self._fp6_option("cheetah_fp6_invert_batch", a)
+
+    def fp6_sqrt_batch(self, a):
+        """(out, is_some): out[i] = the root Fp6::sqrt returns (src/fp6.rs:922-964), is_some[i] = 0 and
+        out[i] = 0 for a non-square"""
+        return self._fp6_option("cheetah_fp6_sqrt_batch", a)
 
     # -- batch_normalize --------------------------------------------------------
     def batch_normalize(self, xyz, form):
@@ -328,6 +336,39 @@ class Engine:
                                                                 some.ctypes.data, n, int(checked)))
         return xy, inf, some
 
+    def from_compressed_batch(self, b, checked=True):
+        """(xy, inf, is_some): AffinePoint::from_compressed (checked: torsion free, src/curve/affine.rs:303-309)
+        or from_compressed_unchecked = CompressedPoint::to_affine (src/curve/encoding.rs:82-129)."""
+        if _is_torch(b):
+            b = self._dev(b, 1, 49)
+            n = b.shape[0]
+            xy, inf, some = self._empty((n, 12), torch.uint64), self._empty((n,), torch.uint8), self._empty((n,), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_decode_compressed_batch_dev(self._h, b.data_ptr(), xy.data_ptr(), inf.data_ptr(),
+                                                                      some.data_ptr(), n, int(checked)))
+            return xy, inf, some
+        b = self._np(b, np.uint8, 49)
+        n = len(b)
+        xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        self._check(self._lib.cheetah_decode_compressed_batch(self._h, b.ctypes.data, xy.ctypes.data, inf.ctypes.data,
+                                                              some.ctypes.data, n, int(checked)))
+        return xy, inf, some
+
+    def from_x_batch(self, x):
+        """(xy, inf, is_some): AffinePoint::from_x (src/curve/affine.rs:326-343)."""
+        if _is_torch(x):
+            x = self._dev(x, 8, 6)
+            n = x.shape[0]
+            xy, inf, some = self._empty((n, 12), torch.uint64), self._empty((n,), torch.uint8), self._empty((n,), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_affine_from_x_batch_dev(self._h, x.data_ptr(), xy.data_ptr(), inf.data_ptr(), some.data_ptr(), n))
+            return xy, inf, some
+        x = self._np(x, np.uint64, 6)
+        n = len(x)
+        xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        self._check(self._lib.cheetah_affine_from_x_batch(self._h, x.ctypes.data, xy.ctypes.data, inf.ctypes.data, some.ctypes.data, n))
+        return xy, inf, some
+
     # -- tables / synthetic inputs / diagnostics -------------------------------------
     def read_table(self, which):
         n = {0: 256, 1: 3, 2: 128, 3: 64}[which]
@@ -402,6 +443,10 @@ class Fp6:
     @staticmethod
     def invert_batch(a, engine=None):
         return (engine or default_engine()).fp6_invert_batch(a)
+
+    @staticmethod
+    def sqrt_batch(a, engine=None):
+        return (engine or default_engine()).fp6_sqrt_batch(a)
 
 
 class ProjectivePoint:
@@ -504,6 +549,18 @@ class AffinePoint:
     @staticmethod
     def from_uncompressed_unchecked_batch(b, engine=None):
         return (engine or default_engine()).from_uncompressed_batch(b, False)
+
+    @staticmethod
+    def from_compressed_batch(b, engine=None):
+        return (engine or default_engine()).from_compressed_batch(b, True)
+
+    @staticmethod
+    def from_compressed_unchecked_batch(b, engine=None):
+        return (engine or default_engine()).from_compressed_batch(b, False)
+
+    @staticmethod
+    def from_x_batch(x, engine=None):
+        return (engine or default_engine()).from_x_batch(x)
 
     @staticmethod
     def multiply_batch(points, scalars, engine=None):

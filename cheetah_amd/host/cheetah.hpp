@@ -91,6 +91,13 @@ inline std::vector<Fp6> fp6_invert_batch(const Context& ctx, const std::vector<F
     ctx.check(cheetah_fp6_invert_batch(ctx.get(), u64p(a.data()), u64p(out.data()), is_some.data(), a.size()));
     return out;
 }
+// out[i] = sqrt(a[i]), is_some[i]  Fp6::sqrt -> CtOption, src/fp6.rs:922-964
+inline std::vector<Fp6> fp6_sqrt_batch(const Context& ctx, const std::vector<Fp6>& a, std::vector<uint8_t>& is_some) {
+    std::vector<Fp6> out(a.size());
+    is_some.assign(a.size(), 0);
+    ctx.check(cheetah_fp6_sqrt_batch(ctx.get(), u64p(a.data()), u64p(out.data()), is_some.data(), a.size()));
+    return out;
+}
 
 // ---- batch_normalize ----------------------------------------------------------
 // ProjectivePoint::batch_normalize(p, q), src/curve/projective.rs:897-930
@@ -226,6 +233,62 @@ inline std::vector<ProjectivePoint> clear_cofactor_batch(const Context& ctx, con
     std::vector<ProjectivePoint> out(p.size());
     ctx.check(cheetah_clear_cofactor_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, u64p(out.data()), nullptr, p.size(),
                                            CHEETAH_PROJECTIVE));
+    return out;
+}
+
+// ---- point encodings (src/curve/encoding.rs) ---------------------------------------
+struct CompressedPoint {
+    std::array<uint8_t, 49> bytes;  // src/curve/encoding.rs:29
+};
+struct UncompressedPoint {
+    std::array<uint8_t, 97> bytes;  // src/curve/encoding.rs:153
+};
+// AffinePoint::to_compressed, src/curve/encoding.rs:55-77
+inline std::vector<CompressedPoint> to_compressed_batch(const Context& ctx, const std::vector<AffinePoint>& p,
+                                                        const std::vector<uint8_t>& infinity) {
+    if (p.size() != infinity.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<CompressedPoint> out(p.size());
+    ctx.check(cheetah_encode_compressed_batch(ctx.get(), u64p(p.data()), infinity.data(), out.data()->bytes.data(), p.size()));
+    return out;
+}
+// AffinePoint::to_uncompressed, src/curve/encoding.rs:169-183
+inline std::vector<UncompressedPoint> to_uncompressed_batch(const Context& ctx, const std::vector<AffinePoint>& p,
+                                                            const std::vector<uint8_t>& infinity) {
+    if (p.size() != infinity.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<UncompressedPoint> out(p.size());
+    ctx.check(cheetah_encode_uncompressed_batch(ctx.get(), u64p(p.data()), infinity.data(), out.data()->bytes.data(), p.size()));
+    return out;
+}
+// AffinePoint::from_compressed (checked, src/curve/affine.rs:303-309) / from_compressed_unchecked (:315-317);
+// is_some[i] = 0 marks a CtOption::none
+inline std::vector<AffinePoint> from_compressed_batch(const Context& ctx, const std::vector<CompressedPoint>& b,
+                                                      std::vector<uint8_t>& infinity, std::vector<uint8_t>& is_some,
+                                                      bool checked = true) {
+    std::vector<AffinePoint> out(b.size());
+    infinity.assign(b.size(), 0);
+    is_some.assign(b.size(), 0);
+    ctx.check(cheetah_decode_compressed_batch(ctx.get(), b.data()->bytes.data(), u64p(out.data()), infinity.data(), is_some.data(),
+                                              b.size(), checked ? 1 : 0));
+    return out;
+}
+// AffinePoint::from_uncompressed (checked, src/curve/affine.rs:289-292) / from_uncompressed_unchecked (:298-300)
+inline std::vector<AffinePoint> from_uncompressed_batch(const Context& ctx, const std::vector<UncompressedPoint>& b,
+                                                        std::vector<uint8_t>& infinity, std::vector<uint8_t>& is_some,
+                                                        bool checked = true) {
+    std::vector<AffinePoint> out(b.size());
+    infinity.assign(b.size(), 0);
+    is_some.assign(b.size(), 0);
+    ctx.check(cheetah_decode_uncompressed_batch(ctx.get(), b.data()->bytes.data(), u64p(out.data()), infinity.data(),
+                                                is_some.data(), b.size(), checked ? 1 : 0));
+    return out;
+}
+// AffinePoint::from_x, src/curve/affine.rs:326-343
+inline std::vector<AffinePoint> from_x_batch(const Context& ctx, const std::vector<Fp6>& x, std::vector<uint8_t>& infinity,
+                                             std::vector<uint8_t>& is_some) {
+    std::vector<AffinePoint> out(x.size());
+    infinity.assign(x.size(), 0);
+    is_some.assign(x.size(), 0);
+    ctx.check(cheetah_affine_from_x_batch(ctx.get(), u64p(x.data()), u64p(out.data()), infinity.data(), is_some.data(), x.size()));
     return out;
 }
 

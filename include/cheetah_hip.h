@@ -67,13 +67,17 @@ const char *cheetah_version(void);
 /* ---- elementwise Fp6 -----------------------------------------------------
  * out[i] = a[i] * b[i]           Fp6::mul      src/fp6.rs:651-834
  * out[i] = a[i]^2                Fp6::square   src/fp6.rs:838-920
- * out[i] = a[i]^-1, is_some[i]   Fp6::invert   src/fp6.rs:1035-1049 (0 -> out = 0, is_some = 0) */
+ * out[i] = a[i]^-1, is_some[i]   Fp6::invert   src/fp6.rs:1035-1049 (0 -> out = 0, is_some = 0)
+ * out[i] = sqrt(a[i]), is_some[i] Fp6::sqrt    src/fp6.rs:922-964 over Fp3::sqrt src/fp3.rs:247-277: the root the
+ *                                reference's algorithm returns (not its negative); non-square -> out = 0, is_some = 0 */
 int32_t cheetah_fp6_mul_batch(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 int32_t cheetah_fp6_square_batch(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 int32_t cheetah_fp6_invert_batch(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
 int32_t cheetah_fp6_mul_batch_dev(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 int32_t cheetah_fp6_square_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 int32_t cheetah_fp6_invert_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
+int32_t cheetah_fp6_sqrt_batch(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
+int32_t cheetah_fp6_sqrt_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
 
 /* ---- batch_normalize -----------------------------------------------------
  * xy[i], inf[i] = affine form of xyz[i]; identities (z = 0) give (0, 1, inf = 1).
@@ -181,16 +185,26 @@ int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, 
  *                                    checked = 1: AffinePoint::from_uncompressed: also is_on_curve and is_torsion_free
  *                                                 (src/curve/affine.rs:289-292)
  *                                    is_some[i] = 0 marks a CtOption::none; its point is written as (0, 0, inf = 0).
- * Decompression of the 49-byte form needs Fp6::sqrt and is not built yet.
+ * cheetah_decode_compressed_batch    checked = 0: AffinePoint::from_compressed_unchecked = CompressedPoint::to_affine    :82-129
+ *                                                 (y = Fp6::sqrt(x^3 + x + B), sign chosen by flag bit 6)
+ *                                    checked = 1: AffinePoint::from_compressed: also is_torsion_free (src/curve/affine.rs:303-309)
+ * cheetah_affine_from_x_batch        AffinePoint::from_x (src/curve/affine.rs:326-343): x = 0 -> identity, else the point with the
+ *                                    lexicographically largest y; is_some = 0 when x^3 + x + B is not a square
  * `_dev`: xy 16-byte aligned, byte arrays 4-byte aligned. */
 int32_t cheetah_encode_uncompressed_batch(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out97, size_t n);
 int32_t cheetah_encode_compressed_batch(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out49, size_t n);
 int32_t cheetah_decode_uncompressed_batch(cheetah_ctx *ctx, const uint8_t *in97, uint64_t *xy, uint8_t *inf, uint8_t *is_some,
                                           size_t n, int checked);
+int32_t cheetah_decode_compressed_batch(cheetah_ctx *ctx, const uint8_t *in49, uint64_t *xy, uint8_t *inf, uint8_t *is_some,
+                                        size_t n, int checked);
+int32_t cheetah_affine_from_x_batch(cheetah_ctx *ctx, const uint64_t *x, uint64_t *xy, uint8_t *inf, uint8_t *is_some, size_t n);
 int32_t cheetah_encode_uncompressed_batch_dev(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out97, size_t n);
 int32_t cheetah_encode_compressed_batch_dev(cheetah_ctx *ctx, const uint64_t *xy, const uint8_t *inf, uint8_t *out49, size_t n);
 int32_t cheetah_decode_uncompressed_batch_dev(cheetah_ctx *ctx, const uint8_t *in97, uint64_t *xy, uint8_t *inf,
                                               uint8_t *is_some, size_t n, int checked);
+int32_t cheetah_decode_compressed_batch_dev(cheetah_ctx *ctx, const uint8_t *in49, uint64_t *xy, uint8_t *inf, uint8_t *is_some,
+                                            size_t n, int checked);
+int32_t cheetah_affine_from_x_batch_dev(cheetah_ctx *ctx, const uint64_t *x, uint64_t *xy, uint8_t *inf, uint8_t *is_some, size_t n);
 
 /* ---- precomputed tables (read back for inspection / tests) ----------------
  * which: 0 = BASEPOINT_TABLE (256 affine points, table-major, src/lookup.rs:136),

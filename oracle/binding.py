@@ -109,6 +109,14 @@ def lib():
         "ora_multiply_vartime_batch": (None, [u64p, C.c_int, u8p, u64p, u8p, C.c_size_t, C.c_int]),
         "ora_odd_multiples_basepoint": (C.POINTER(C.c_uint64), []),
         "ora_fp6_lexicographically_largest": (C.c_int, [u64p]),
+        "ora_fp3_mul": (C.c_int, [u64p, u64p, u64p]),
+        "ora_fp3_sqrt": (C.c_int, [u64p, u64p]),
+        "ora_fp6_sqrt": (C.c_int, [u64p, u64p]),
+        "ora_fp6_sqrt_batch": (None, [u64p, u64p, u8p, C.c_size_t]),
+        "ora_compressed_to_affine": (C.c_int, [u8p, C.c_int, u64p, u8p]),
+        "ora_decode_compressed_batch": (None, [u8p, C.c_int, u64p, u8p, u8p, C.c_size_t]),
+        "ora_affine_from_x": (C.c_int, [u64p, u64p, u8p]),
+        "ora_affine_from_x_batch": (None, [u64p, u64p, u8p, u8p, C.c_size_t]),
         "ora_affine_to_compressed": (None, [u64p, C.c_uint8, u8p]),
         "ora_affine_to_uncompressed": (None, [u64p, C.c_uint8, u8p]),
         "ora_uncompressed_to_affine": (C.c_int, [u8p, C.c_int, u64p, u8p]),
@@ -232,6 +240,30 @@ def decode_uncompressed_batch(b, checked):
     xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
     lib().ora_decode_uncompressed_batch(b, int(checked), xy, inf, some, n)
     return xy, inf, some
+
+
+def decode_compressed_batch(b, checked):
+    b = _u8(b).reshape(-1, 49)
+    n = len(b)
+    xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+    lib().ora_decode_compressed_batch(b, int(checked), xy, inf, some, n)
+    return xy, inf, some
+
+
+def affine_from_x_batch(x):
+    x = _u64(x).reshape(-1, 6)
+    n = len(x)
+    xy, inf, some = np.empty((n, 12), np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint8)
+    lib().ora_affine_from_x_batch(x, xy, inf, some, n)
+    return xy, inf, some
+
+
+def fp6_sqrt_batch(a):
+    a = _u64(a).reshape(-1, 6)
+    out = np.empty_like(a)
+    ok = np.empty(len(a), np.uint8)
+    lib().ora_fp6_sqrt_batch(a, out, ok, len(a))
+    return out, ok
 
 
 def batch_normalize(p, jacobian, chunk=0):

@@ -1424,6 +1424,138 @@ void ora_multiply_many_batch(const u64 *pts, int in_form, const uint8_t *scalars
     }
 }
 
+/* ------------------------------------------------- Fp3, square roots ---- */
+/* Fp3 = Fp[X]/(X^3 - 7), embedded in Fp6 as (c0, c2, c4) (src/fp3.rs:41-48, :112-120). */
+typedef struct { u64 a[3]; } fp3;
+static const fp3 FP3_ZERO = {{0, 0, 0}};
+static const fp3 FP3_ONE = {{1, 0, 0}};
+#define OFF8P ((u128)0x7fffffff8ULL << 32 | 0x00000008ULL) /* 0x7fffffff800000008 = 8p, src/fp3.rs:186 */
+#define OFF8P7 (OFF8P * 7)                                  /* 0x37ffffffc800000038 */
+
+/* The cubic Karatsuba block shared by Fp3::mul (src/fp3.rs:169-211) and
+ * Fp6::mul_by_{low,high}_fp3 (src/fp6.rs:469-647): unreduced d0, d1, d2. */
+static inline void cubic_karatsuba(const u64 x[3], const u64 y[3], u128 *d0, u128 *d1, u128 *d2) {
+    u128 t0 = fp_mul(x[0], y[0]), t1 = fp_mul(x[1], y[1]), t2 = fp_mul(x[2], y[2]);
+    u128 s12 = fp_mul(fp_add(x[1], x[2]), fp_add(y[1], y[2]));
+    u128 s01 = fp_mul(fp_add(x[0], x[1]), fp_add(y[0], y[1]));
+    u128 s02 = fp_mul(fp_add(x[0], x[2]), fp_add(y[0], y[2]));
+    *d0 = (s12 + OFF8P - (t1 + t2)) * 7 + t0;
+    *d1 = t2 * 7 + OFF8P - (t0 + t1) + s01;
+    *d2 = t1 + OFF8P - (t0 + t2) + s02;
+}
+static fp3 fp3_mul(fp3 x, fp3 y) { /* src/fp3.rs:169-211 */
+    u128 d0, d1, d2;
+    cubic_karatsuba(x.a, y.a, &d0, &d1, &d2);
+    fp3 r = {{reduce_u96(d0), reduce_u96(d1), reduce_u96(d2)}};
+    return r;
+}
+static fp3 fp3_square(fp3 x) { return fp3_mul(x, x); } /* src/fp3.rs:215-252 (same values) */
+static int fp3_eq(fp3 x, fp3 y) {
+    return fp_canonical(x.a[0]) == fp_canonical(y.a[0]) && fp_canonical(x.a[1]) == fp_canonical(y.a[1]) &&
+           fp_canonical(x.a[2]) == fp_canonical(y.a[2]);
+}
+static fp3 fp3_exp_vartime(fp3 x, const u64 *power, int nwords) { /* src/fp3.rs:285-297 */
+    fp3 res = FP3_ONE;
+    for (int w = nwords - 1; w >= 0; w--)
+        for (int i = 63; i >= 0; i--) {
+            res = fp3_square(res);
+            if ((power[w] >> i) & 1) res = fp3_mul(res, x);
+        }
+    return res;
+}
+/* Fp3::sqrt, Tonelli-Shanks for 2-adicity 32, src/fp3.rs:255-282 */
+static int fp3_sqrt(fp3 x, fp3 *out) {
+    static const u64 E[3] = {0x80000002fffffffeULL, 0x80000002fffffffcULL, 0x000000007ffffffeULL};
+    fp3 y = fp3_exp_vartime(x, E, 3);
+    fp3 s = fp3_mul(x, y), t = fp3_mul(s, y);
+    fp3 z = {{2800184025912956819ULL, 0, 0}}; /* TWO_ADIC_ROOT_OF_UNITY_P3, src/fp3.rs:33-37 */
+    for (int k = 32; k >= 2; k--) {
+        fp3 b = t;
+        for (int i = 0; i < k - 2; i++) b = fp3_square(b);
+        int is_one = fp3_eq(b, FP3_ONE);
+        fp3 new_s = fp3_mul(s, z);
+        if (!is_one) s = new_s;
+        z = fp3_square(z);
+        fp3 new_t = fp3_mul(t, z);
+        if (!is_one) t = new_t;
+    }
+    *out = s;
+    return fp3_eq(fp3_square(s), x);
+}
+int ora_fp3_mul(const u64 *a, const u64 *b, u64 *o) {
+    fp3 x = {{a[0], a[1], a[2]}}, y = {{b[0], b[1], b[2]}}, r = fp3_mul(x, y);
+    for (int i = 0; i < 3; i++) o[i] = fp_canonical(r.a[i]);
+    return 1;
+}
+int ora_fp3_sqrt(const u64 *a, u64 *o) {
+    fp3 x = {{a[0], a[1], a[2]}}, r;
+    int ok = fp3_sqrt(x, &r);
+    for (int i = 0; i < 3; i++) o[i] = ok ? fp_canonical(r.a[i]) : 0;
+    return ok;
+}
+/* Fp6::mul_by_low_fp3 / mul_by_high_fp3, src/fp6.rs:469-647: (A0 + A1 Y) * f and (A0 + A1 Y) * (f Y), Y^2 = X */
+static fp6 fp6_mul_by_low_fp3(fp6 s, fp3 f) {
+    u64 a0[3] = {s.c[0], s.c[2], s.c[4]}, a1[3] = {s.c[1], s.c[3], s.c[5]};
+    u128 d00, d01, d02, d30, d31, d32;
+    cubic_karatsuba(a0, f.a, &d00, &d01, &d02);
+    cubic_karatsuba(a1, f.a, &d30, &d31, &d32);
+    fp6 r = {{reduce_u96(d00 + OFF8P7), reduce_u96(d30 + OFF8P7), reduce_u96(d01 + OFF8P7), reduce_u96(d31 + OFF8P),
+              reduce_u96(d02 + OFF8P), reduce_u96(d32 + OFF8P)}};
+    return r;
+}
+static fp6 fp6_mul_by_high_fp3(fp6 s, fp3 f) {
+    u64 a0[3] = {s.c[0], s.c[2], s.c[4]}, a1[3] = {s.c[1], s.c[3], s.c[5]};
+    u128 d10, d11, d12, d20, d21, d22;
+    cubic_karatsuba(a1, f.a, &d10, &d11, &d12);
+    cubic_karatsuba(a0, f.a, &d20, &d21, &d22);
+    fp6 r = {{reduce_u96((d12 + OFF8P) * 7), reduce_u96(d20 + OFF8P7), reduce_u96(d10 + OFF8P), reduce_u96(d21 + OFF8P),
+              reduce_u96(d11 + OFF8P), reduce_u96(d22 + OFF8P)}};
+    return r;
+}
+static fp6 fp6_exp_vartime(fp6 x, const u64 *power, int nwords) { /* src/fp6.rs:1072-1084 */
+    fp6 res = FP6_ONE;
+    for (int w = nwords - 1; w >= 0; w--)
+        for (int i = 63; i >= 0; i--) {
+            res = fp6_square(res);
+            if ((power[w] >> i) & 1) res = fp6_mul(res, x);
+        }
+    return res;
+}
+/* Fp6::sqrt, Algorithm 10 of eprint 2012/685 as in src/fp6.rs:922-964 */
+static int fp6_sqrt(fp6 self, fp6 *out) {
+    static const fp3 E = {{17474221990273267221ULL, 11073203528037158631ULL, 1587630551273719300ULL}};
+    static const fp3 F = {{16, 18446744069414584320ULL, 0}};
+    static const u64 EXP[1] = {0x3fffffffc0000000ULL};
+    fp6 b = fp6_mul(self, fp6_frobenius(self));
+    b = fp6_mul(b, fp6_frobenius_double(self));
+    b = fp6_exp_vartime(b, EXP, 1);
+    fp6 b2 = fp6_square(b);
+    fp6 b_pow_p3 = fp6_frobenius_triple(b);
+    fp6 check = fp6_mul(b_pow_p3, b);
+    fp6 s = fp6_mul(b2, self);
+    fp6 sf = fp6_mul_by_low_fp3(s, F);
+    fp3 s3 = {{s.c[0], s.c[2], s.c[4]}}, sf3 = {{sf.c[0], sf.c[2], sf.c[4]}};
+    fp3 sqrt_s, sqrt_sf;
+    if (!fp3_sqrt(s3, &sqrt_s)) sqrt_s = FP3_ZERO;
+    if (!fp3_sqrt(sf3, &sqrt_sf)) sqrt_sf = FP3_ZERO;
+    int is_one = fp6_eq(check, FP6_ONE);
+    fp3 x0 = is_one ? sqrt_s : sqrt_sf;
+    fp6 x = fp6_mul_by_low_fp3(b_pow_p3, x0);
+    if (!is_one) x = fp6_mul_by_high_fp3(x, E);
+    *out = x;
+    return fp6_eq(fp6_square(x), self);
+}
+int ora_fp6_sqrt(const u64 *a, u64 *o) {
+    fp6 r;
+    int ok = fp6_sqrt(fp6_load(a), &r);
+    fp6_store(o, ok ? fp6_canonical(r) : FP6_ZERO);
+    return ok;
+}
+void ora_fp6_sqrt_batch(const u64 *a, u64 *out, uint8_t *is_some, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) is_some[i] = (uint8_t)ora_fp6_sqrt(a + 6 * i, out + 6 * i);
+}
+
 /* ------------------------------------------------------------ encodings ---- */
 
 /* Fp::lexicographically_largest, src/fp.rs:281-300 */
@@ -1500,6 +1632,73 @@ int ora_uncompressed_to_affine(const uint8_t *in97, int checked, u64 *out_xy, ui
     }
     affine_store(out_xy, out_inf, p);
     return ok;
+}
+
+/* CompressedPoint::to_affine (checked = 0: AffinePoint::from_compressed_unchecked, src/curve/encoding.rs:82-129)
+ * and AffinePoint::from_compressed (checked = 1: also torsion free, src/curve/affine.rs:300-309). */
+int ora_compressed_to_affine(const uint8_t *in49, int checked, u64 *out_xy, uint8_t *out_inf) {
+    int inf_flag = (in49[48] >> 7) & 1, sort_flag = (in49[48] >> 6) & 1;
+    fp6 x;
+    int ok = fp6_from_bytes(in49, &x);
+    affine p = affine_identity();
+    if (ok) {
+        if (inf_flag & !sort_flag & fp6_is_zero(x)) {
+            p = affine_identity();
+        } else {
+            fp6 rhs = fp6_add(fp6_add(fp6_mul(fp6_square(x), x), x), CURVE_B), y;
+            ok = fp6_sqrt(rhs, &y);
+            if (ok) {
+                if (fp6_lex_largest(y) ^ sort_flag) y = fp6_neg(y);
+                p.x = x;
+                p.y = y;
+                p.inf = (uint8_t)inf_flag;
+                ok = !inf_flag;
+            }
+        }
+    }
+    if (ok && checked) {
+        static const uint8_t QB[32] = {207, 172, 212, 174, 62, 98, 67, 212, 34, 119, 21, 48, 35, 167, 122, 50,
+                                       181, 55, 10, 153, 15, 191, 63, 86, 208, 34, 63, 59, 155, 89, 242, 122};
+        proj r = jac_multiply_vartime(proj_from_affine(p), QB);
+        ok &= fp6_is_zero(r.z);
+    }
+    if (!ok) {
+        affine z = {FP6_ZERO, FP6_ZERO, 0};
+        p = z;
+    }
+    affine_store(out_xy, out_inf, p);
+    return ok;
+}
+/* AffinePoint::from_x, src/curve/affine.rs:326-343 */
+int ora_affine_from_x(const u64 *x6, u64 *out_xy, uint8_t *out_inf) {
+    fp6 x = fp6_load(x6);
+    affine p = affine_identity();
+    int ok = 1;
+    if (!fp6_is_zero(x)) {
+        fp6 rhs = fp6_add(fp6_add(fp6_mul(fp6_square(x), x), x), CURVE_B), y;
+        ok = fp6_sqrt(rhs, &y);
+        if (ok) {
+            if (!fp6_lex_largest(y)) y = fp6_neg(y);
+            p.x = x;
+            p.y = y;
+            p.inf = 0;
+        }
+    }
+    if (!ok) {
+        affine z = {FP6_ZERO, FP6_ZERO, 0};
+        p = z;
+    }
+    affine_store(out_xy, out_inf, p);
+    return ok;
+}
+void ora_affine_from_x_batch(const u64 *x, u64 *xy, uint8_t *inf, uint8_t *is_some, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) is_some[i] = (uint8_t)ora_affine_from_x(x + 6 * i, xy + 12 * i, inf + i);
+}
+void ora_decode_compressed_batch(const uint8_t *in, int checked, u64 *xy, uint8_t *inf, uint8_t *is_some, size_t n) {
+    ora_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) is_some[i] = (uint8_t)ora_compressed_to_affine(in + 49 * i, checked, xy + 12 * i, inf + i);
 }
 void ora_encode_batch(const u64 *xy, const uint8_t *inf, uint8_t *out, size_t n, int compressed) {
 #pragma omp parallel for schedule(static)

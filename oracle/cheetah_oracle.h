@@ -135,6 +135,16 @@ void ora_multiply_vartime_batch(const uint64_t *pts, int in_form, const uint8_t 
  * (src/curve/projective.rs:693-809, :840-869, src/curve/jacobian.rs:681-858).  m <= 64. */
 void ora_multiply_many_batch(const uint64_t *pts, int in_form, const uint8_t *scalars, int m, int vartime, int with_basepoint,
                              uint64_t *out, uint8_t *out_inf, size_t n_groups, int out_form);
+/* ---- Fp3 and square roots (src/fp3.rs, src/fp6.rs:922-964) ---- */
+int ora_fp3_mul(const uint64_t *a, const uint64_t *b, uint64_t *out);   /* src/fp3.rs:169-211; canonical out */
+int ora_fp3_sqrt(const uint64_t *a, uint64_t *out);                     /* src/fp3.rs:255-282; returns is_some */
+int ora_fp6_sqrt(const uint64_t *a, uint64_t *out);                     /* src/fp6.rs:922-964; returns is_some, out = 0 if none */
+void ora_fp6_sqrt_batch(const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
+int ora_compressed_to_affine(const uint8_t *in49, int checked, uint64_t *out_xy, uint8_t *out_inf); /* encoding.rs:82-129, affine.rs:300-309 */
+void ora_decode_compressed_batch(const uint8_t *in, int checked, uint64_t *xy, uint8_t *inf, uint8_t *is_some, size_t n);
+int ora_affine_from_x(const uint64_t *x6, uint64_t *out_xy, uint8_t *out_inf);                      /* src/curve/affine.rs:326-343 */
+void ora_affine_from_x_batch(const uint64_t *x, uint64_t *xy, uint8_t *inf, uint8_t *is_some, size_t n);
+
 /* ---- point encodings (src/curve/encoding.rs) ---- */
 int ora_fp6_lexicographically_largest(const uint64_t *a);                                   /* src/fp6.rs:398-424 */
 void ora_affine_to_compressed(const uint64_t *xy, uint8_t inf, uint8_t *out49);             /* encoding.rs:55-77 */

@@ -80,6 +80,27 @@ int main() {
         std::vector<JacobianPoint> jchk = {jl[0]};
         batch_normalize(ctx, jchk, q, infinity);
         EXPECT(q[0].x.c == x2.c && q[0].y.c == y2.c);
+        // encodings: identity byte strings (src/curve/projective.rs:1533-1539, :1575-1582), 2G -> 49 bytes -> 2G,
+        // sqrt(1) = 1 and u + 2 is a non-square (src/fp6.rs:1561-1577), from_x(1) is none (src/curve/affine.rs:645-653)
+        {
+            std::vector<AffinePoint> ap = {g2[0], AffinePoint{zero, one}};
+            std::vector<uint8_t> ainf = {0, 1}, dinf, dsome;
+            auto cp = to_compressed_batch(ctx, ap, ainf);
+            auto up = to_uncompressed_batch(ctx, ap, ainf);
+            bool id_ok = cp[1].bytes[48] == 128 && up[1].bytes[96] == 128;
+            for (int i = 0; i < 48; i++) id_ok = id_ok && cp[1].bytes[i] == 0;
+            for (int i = 0; i < 96; i++) id_ok = id_ok && up[1].bytes[i] == 0;
+            EXPECT(id_ok);
+            auto dp = from_compressed_batch(ctx, cp, dinf, dsome, true);
+            EXPECT(dsome[0] == 1 && dsome[1] == 1 && dp[0].x.c == x2.c && dp[0].y.c == y2.c && dinf[0] == 0 && dinf[1] == 1);
+            auto du = from_uncompressed_batch(ctx, up, dinf, dsome, true);
+            EXPECT(dsome[0] == 1 && dsome[1] == 1 && du[0].x.c == x2.c && du[0].y.c == y2.c && dinf[1] == 1);
+            Fp6 nsq{{2, 1, 0, 0, 0, 0}};
+            auto rt = fp6_sqrt_batch(ctx, {one, nsq, zero}, dsome);
+            EXPECT(rt[0].c == one.c && dsome[0] == 1 && dsome[1] == 0 && rt[1].c == zero.c && dsome[2] == 1 && rt[2].c == zero.c);
+            auto fx = from_x_batch(ctx, {one, zero, x2}, dinf, dsome);
+            EXPECT(dsome[0] == 0 && dsome[1] == 1 && dinf[1] == 1 && dsome[2] == 1 && fx[2].x.c == x2.c);
+        }
         // length mismatch is an error, not UB
         bool threw = false;
         try {

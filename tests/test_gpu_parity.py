@@ -587,6 +587,72 @@ def test_encodings_vs_oracle(eng, ora, kats, n):
         assert list(wsome[:6]) == [0, 0, 0, 1, 1, 0]
 
 
+@pytest.mark.parametrize("n", [1, 255, 777])
+def test_sqrt_decompression_from_x_vs_oracle(eng, ora, kats, n):
+    """SURVEY 8 f-3: Fp6::sqrt (src/fp6.rs:922-964 over Fp3::sqrt src/fp3.rs:247-277), CompressedPoint::to_affine /
+    AffinePoint::from_compressed (src/curve/encoding.rs:82-129, src/curve/affine.rs:303-309), AffinePoint::from_x
+    (:326-343): squares, non-squares, edge limbs, the reference's rejection KATs, ragged sizes; bit-exact vs the oracle."""
+    a = edge_fp6(n, 61)
+    sq = host(eng.fp6_square_batch(dev(a)))
+    mixed = np.concatenate([sq, a])
+    wr, ws = ora.fp6_sqrt_batch(mixed)
+    gr, gs = eng.fp6_sqrt_batch(dev(mixed))
+    assert (host(gr) == wr).all() and (host(gs) == ws).all()
+    assert ws[:n].all()
+    hr, hs = eng.fp6_sqrt_batch(mixed)
+    assert (hr == wr).all() and (hs == ws).all()
+    kk = kats["fp3"]
+    r, s_ = eng.fp6_sqrt_batch(np.array([kk["non_square_fp6"], [0] * 6, [1, 0, 0, 0, 0, 0], [P, P, P, P, P, P]], np.uint64))
+    assert list(s_) == [0, 1, 1, 1] and not r[0].any() and not r[1].any() and list(r[2]) == [1, 0, 0, 0, 0, 0] and not r[3].any()
+    # compressed round trip + rejection cases
+    xy, inf = ora.mul_by_generator_batch(synth.scalars(62, n), 0)
+    xy, inf = xy.copy(), inf.copy()
+    if n > 8:
+        xy[5] = [0] * 6 + [1] + [0] * 5
+        inf[5] = 1
+    enc = ora.encode_batch(xy, inf, True)
+    for checked in (False, True):
+        gxy, ginf, gsome = eng.from_compressed_batch(dev(enc), checked)
+        assert (host(gxy) == xy).all() and (host(ginf) == inf).all() and host(gsome).all(), checked
+    if n > 8:
+        ns = np.array([kats["non_subgroup_point"]["x"] + kats["non_subgroup_point"]["y"]], np.uint64)
+        enc[0, 0:8] = 0xFF
+        enc[1, 48] |= 0x80
+        enc[2] = 0
+        enc[2, 48] = 0xC0
+        enc[3] = ora.encode_batch(ns, np.zeros(1, np.uint8), True)[0]
+        enc[4, 48] ^= 0x40
+        enc[6] = 0      # x = 0 without the flag: B is a non-square (src/curve/encoding.rs:385-396)
+        enc[7] = 0xFF   # src/curve/affine.rs:692-696
+    for checked in (False, True):
+        wxy, winf, wsome = ora.decode_compressed_batch(enc, checked)
+        gxy, ginf, gsome = eng.from_compressed_batch(dev(enc), checked)
+        assert (host(gxy) == wxy).all() and (host(ginf) == winf).all() and (host(gsome) == wsome).all(), checked
+        hxy, hinf, hsome = eng.from_compressed_batch(enc, checked)
+        assert (hxy == wxy).all() and (hinf == winf).all() and (hsome == wsome).all()
+        if n > 8:
+            assert list(wsome[:8]) == [0, 0, 0, 0 if checked else 1, 1, 1, 0, 0]
+    # from_x
+    xs = np.concatenate([xy[:, :6], np.array(kats["decompression"]["from_x_none"], np.uint64), np.zeros((1, 6), np.uint64), a])
+    wxy, winf, wsome = ora.affine_from_x_batch(xs)
+    gxy, ginf, gsome = eng.from_x_batch(dev(xs))
+    assert (host(gxy) == wxy).all() and (host(ginf) == winf).all() and (host(gsome) == wsome).all()
+    hxy, hinf, hsome = eng.from_x_batch(xs)
+    assert (hxy == wxy).all() and (hinf == winf).all() and (hsome == wsome).all()
+    assert wsome[n] == 0 and wsome[n + 1] == 1 and winf[n + 1] == 1
+
+
+def test_compress_decompress_round_trip_large(eng):
+    """Size-independent property at 2^18 points: k_i G -> 49 bytes -> from_compressed (checked) gives the points back."""
+    import torch
+    from cheetah_amd import AFFINE
+    n = 1 << 18
+    pts, inf = eng.mul_by_generator_batch(eng.synth_scalars(63, n), AFFINE)
+    enc = eng.to_compressed_batch(pts, inf)
+    xy, i2, some = eng.from_compressed_batch(enc, True)
+    assert bool(some.all()) and torch.equal(xy.view(torch.int64), pts.view(torch.int64)) and torch.equal(i2, inf)
+
+
 # ----------------------------------------- BASELINE-size property checks ----
 
 def test_full_size_configs_2_3_properties(eng, ora):

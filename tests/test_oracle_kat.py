@@ -416,3 +416,111 @@ def test_multi_scalar_ladders_vs_single(ora):
     comb = np.array([list(((int.from_bytes(bytes(ab[2 * i]), "little") * int.from_bytes(bytes(r[i]), "little")
                             + int.from_bytes(bytes(ab[2 * i + 1]), "little")) % Q).to_bytes(32, "little")) for i in range(n)], np.uint8)
     assert (got == ora.mul_by_generator_batch(comb, 0)[0]).all()
+
+
+def _emb3(a):
+    """Fp3 element (a0, a1, a2) embedded in Fp6 as (c0, c2, c4) (src/fp3.rs:112-120)."""
+    return (int(a[0]) % P, 0, int(a[1]) % P, 0, int(a[2]) % P, 0)
+
+
+def test_fp3_and_sqrt_kats(ora, kats):
+    """Fp3 mul / square KATs (src/fp3.rs:437-450, :477-509), the 2^32-th root of unity (:515-525), the
+    non-squares of Fp3 and Fp6 (src/fp3.rs:463-473, src/fp6.rs:1564-1577), sqrt(0) = 0, sqrt(1) = 1, and
+    seeded squares / non-squares against the big-integer model (root^2 = a; Euler's criterion)."""
+    L = ora.lib()
+    k = kats["fp3"]
+    o = np.zeros(3, np.uint64)
+    L.ora_fp3_mul(u64(k["mul"]["a"]), u64(k["mul"]["b"]), o)
+    assert list(o) == k["mul"]["out"]
+    L.ora_fp3_mul(u64(k["square"]["a"]), u64(k["square"]["a"]), o)
+    assert list(o) == k["square"]["out"]
+    L.ora_fp3_mul(u64([1, 3, 5]), u64([1, 0, 0]), o)
+    assert list(o) == [1, 3, 5]
+    z = k["two_adic_root_of_unity"]
+    assert pow(z, 1 << 32, P) == 1 and pow(z, (1 << 32) - 1, P) != 1 and pow(z, 1 << 31, P) == P - 1
+    assert L.ora_fp3_sqrt(u64(k["non_square_fp3"]), o) == 0
+    assert L.ora_fp3_sqrt(u64([0, 0, 0]), o) == 1 and list(o) == [0, 0, 0]
+    assert L.ora_fp3_sqrt(u64([1, 0, 0]), o) == 1 and list(o) == [1, 0, 0]
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        a = [int(v) % P for v in rng.integers(0, 2**64, 3, dtype=np.uint64)]
+        b = [int(v) % P for v in rng.integers(0, 2**64, 3, dtype=np.uint64)]
+        L.ora_fp3_mul(u64(a), u64(b), o)
+        want = M.f6_mul(_emb3(a), _emb3(b))
+        assert _emb3(o) == want
+        sq = M.f6_sqr(_emb3(a))
+        assert L.ora_fp3_sqrt(u64([sq[0], sq[2], sq[4]]), o) == 1
+        assert M.f6_sqr(_emb3(o)) == sq
+    o6 = np.zeros(6, np.uint64)
+    assert L.ora_fp6_sqrt(u64(k["non_square_fp6"]), o6) == 0 and not o6.any()
+    assert L.ora_fp6_sqrt(u64([0] * 6), o6) == 1 and list(o6) == [0] * 6
+    assert L.ora_fp6_sqrt(u64([1, 0, 0, 0, 0, 0]), o6) == 1 and list(o6) == [1, 0, 0, 0, 0, 0]
+    a = synth.fp6_elements(41, 24)
+    sq = np.array([M.f6_sqr(M.f6(r)) for r in a[:12]], np.uint64)
+    mixed = np.concatenate([sq, a[12:]])
+    roots, some = ora.fp6_sqrt_batch(mixed)
+    assert some[:12].all()
+    euler = (P ** 6 - 1) // 2
+    for i in range(len(mixed)):
+        is_sq = M.f6_pow(M.f6(mixed[i]), euler) == M.ONE
+        assert bool(some[i]) == is_sq, i
+        if is_sq:
+            assert M.f6_sqr(M.f6(roots[i])) == M.f6(mixed[i])
+        else:
+            assert not roots[i].any()
+
+
+def test_decompression_and_from_x(ora, kats):
+    """CompressedPoint::to_affine / AffinePoint::from_compressed (src/curve/encoding.rs:82-129,
+    src/curve/affine.rs:303-309) and AffinePoint::from_x (:326-343): round trips on seeded subgroup points
+    (the reference's test shape, src/curve/encoding.rs:359-397, src/curve/affine.rs:627-697), its rejection KATs,
+    the non-subgroup point (accepted unchecked, rejected checked), and the recovered y checked on the curve by the model."""
+    n = 24
+    xy, inf = ora.mul_by_generator_batch(synth.scalars(51, n), 0)
+    xy, inf = xy.copy(), inf.copy()
+    xy[5] = [0] * 6 + [1] + [0] * 5
+    inf[5] = 1
+    enc = ora.encode_batch(xy, inf, True)
+    for checked in (0, 1):
+        dxy, dinf, some = ora.decode_compressed_batch(enc, checked)
+        assert some.all() and (dxy == xy).all() and (dinf == inf).all()
+    d = kats["decompression"]
+    bad = np.array(d["compressed_none"], np.uint8)
+    for checked in (0, 1):
+        dxy, dinf, some = ora.decode_compressed_batch(bad, checked)
+        assert not some.any() and not dxy.any() and not dinf.any()
+    ns = np.array([kats["non_subgroup_point"]["x"] + kats["non_subgroup_point"]["y"]], np.uint64)
+    cases = enc[:5].copy()
+    cases[0, 0:8] = 0xFF            # non-canonical limb
+    cases[1, 48] |= 0x80            # infinity flag over a non-zero x
+    cases[2] = 0
+    cases[2, 48] = 0xC0             # infinity flag and sort flag
+    cases[3] = ora.encode_batch(ns, np.zeros(1, np.uint8), True)[0]
+    cases[4, 48] ^= 0x40            # other root: the negated point, still in the subgroup
+    dxy0, _, some0 = ora.decode_compressed_batch(cases, 0)
+    dxy1, _, some1 = ora.decode_compressed_batch(cases, 1)
+    assert list(some0) == [0, 0, 0, 1, 1] and list(some1) == [0, 0, 0, 0, 1]
+    assert (dxy0[3] == ns[0]).all()
+    assert list(dxy0[4, :6]) == list(xy[4, :6]) and [int(v) for v in dxy0[4, 6:]] == [(P - int(v)) % P for v in xy[4, 6:]]
+    # from_x
+    xs = np.concatenate([xy[:, :6], np.array(d["from_x_none"], np.uint64), np.zeros((1, 6), np.uint64), synth.fp6_elements(52, 8)])
+    fxy, finf, fsome = ora.affine_from_x_batch(xs)
+    L = ora.lib()
+    for i in range(n):
+        if i == 5:
+            continue
+        assert fsome[i] and (fxy[i, :6] == xy[i, :6]).all()
+        y = [int(v) for v in xy[i, 6:]]
+        want = y if L.ora_fp6_lexicographically_largest(np.array(y, np.uint64)) else [(P - v) % P for v in y]
+        assert [int(v) for v in fxy[i, 6:]] == want
+    assert fsome[5] and finf[5] == 1 and list(fxy[5]) == [0] * 6 + [1] + [0] * 5     # x = 0: the identity
+    assert fsome[n] == 0 and not fxy[n].any()                                          # from_x(1): none
+    assert fsome[n + 1] == 1 and finf[n + 1] == 1
+    for i in range(n + 2, len(xs)):                                                    # arbitrary x: on the curve or none
+        if fsome[i]:
+            pt = (M.f6(fxy[i, :6]), M.f6(fxy[i, 6:]))
+            assert M.is_on_curve(pt) and L.ora_fp6_lexicographically_largest(np.ascontiguousarray(fxy[i, 6:])) == 1
+        else:
+            rhs = M.f6_add(M.f6_add(M.f6_mul(M.f6_sqr(M.f6(xs[i])), M.f6(xs[i])), M.f6(xs[i])), M.B)
+            assert M.f6_pow(rhs, (P ** 6 - 1) // 2) != M.ONE
+    assert 0 < fsome[n + 2:].sum() < 8
