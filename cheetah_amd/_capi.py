@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcheetah_hip.so")
+# CHEETAH_HIP_LIB: another build of the SAME library (A/B timing of kernel variants under tools/); never a fallback
+LIB_PATH = os.environ.get("CHEETAH_HIP_LIB") or os.path.join(_HERE, "lib", "libcheetah_hip.so")
 
 AFFINE, PROJECTIVE, JACOBIAN = 0, 1, 2
 

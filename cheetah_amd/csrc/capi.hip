@@ -326,7 +326,7 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         case 0: LAUNCH(KERN, MJac, 0, 0); break; /* A -> A */ \
         case 1: LAUNCH(KERN, Proj, 0, 1); break; /* A -> P */ \
         case 2: LAUNCH(KERN, MJac, 0, 2); break; /* A -> J */ \
-        case 3: LAUNCH(KERN, Proj, 1, 0); break; /* P -> A */ \
+        case 3: LAUNCH(KERN, MJac, 1, 0); break; /* P -> A: the affine point is the same on either accumulator; MJac is cheaper */ \
         case 4: LAUNCH(KERN, Proj, 1, 1); break; /* P -> P */ \
         case 6: LAUNCH(KERN, MJac, 2, 0); break; /* J -> A */ \
         default: LAUNCH(KERN, MJac, 2, 2); break; /* J -> J */ \

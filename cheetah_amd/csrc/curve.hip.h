@@ -202,6 +202,33 @@ CH_DEV MJac mjac_double_unchecked(const MJac& s) {
     return o;
 }
 
+// The same doubling without its last product: z4 is left stale.  Only valid when the next
+// operation is mjac_add_mixed_unchecked_fresh_z4 (which rebuilds z^4 from z) or the point is
+// emitted (a JacobianPoint has no z4, src/curve/jacobian.rs:118-126).  x, y, z are unchanged.
+CH_DEV MJac mjac_double_unchecked_stale_z4(const MJac& s) {
+    Fp6 x_sq = fp6_square(s.x);
+    Fp6 y_sq = fp6_square(s.y);
+    Fp6 y_sq2 = fp6_square(y_sq);
+    Fp6 a = fp6_mul_small(y_sq, 4u);
+    a = fp6_mul(a, s.x);
+    Fp6 b = fp6_triple(x_sq);
+    b = fp6_add(b, s.z4);
+    Fp6 c = fp6_mul_small(y_sq2, 8u);
+    Fp6 x3 = fp6_square(b);
+    x3 = fp6_sub(x3, fp6_double(a));
+    Fp6 y3 = fp6_sub(a, x3);
+    y3 = fp6_mul(y3, b);
+    y3 = fp6_sub(y3, c);
+    Fp6 z3 = fp6_double(s.y);
+    z3 = fp6_mul(z3, s.z);
+    MJac o;
+    o.x = x3;
+    o.y = y3;
+    o.z = z3;
+    o.z4 = s.z4;
+    return o;
+}
+
 // src/curve/jacobian.rs:1146-1186
 CH_DEV MJac mjac_add_mixed_unchecked(const MJac& s, const Affine& r) {
     Fp6 z1_sq = fp6_square(s.z);
@@ -228,6 +255,39 @@ CH_DEV MJac mjac_add_mixed_unchecked(const MJac& s, const Affine& r) {
     o.y = fp6_select(y3, s.y, r.inf);
     o.z = fp6_select(z3, s.z, r.inf);
     o.z4 = fp6_select(z34, s.z4, r.inf);
+    return o;
+}
+
+// The same addition for an accumulator whose z4 is stale: z^4 is rebuilt from the z that is
+// returned, so it is right for the identity operand too (the reference returns self there,
+// whose z4 = z^4 by construction).  WANT_Z4 = false: the result is emitted, z4 is not needed.
+template <bool WANT_Z4>
+CH_DEV MJac mjac_add_mixed_unchecked_fresh_z4(const MJac& s, const Affine& r) {
+    Fp6 z1_sq = fp6_square(s.z);
+    Fp6 b = fp6_mul(r.x, z1_sq);
+    Fp6 d = fp6_mul(s.z, z1_sq);
+    d = fp6_mul(d, r.y);
+    Fp6 e = fp6_sub(b, s.x);
+    Fp6 f = fp6_sub(d, s.y);
+    Fp6 e_sq = fp6_square(e);
+    Fp6 e_sq_e = fp6_mul(e, e_sq);
+    Fp6 x_e_sq = fp6_mul(s.x, e_sq);
+    Fp6 x3 = fp6_square(f);
+    x3 = fp6_sub(x3, e_sq_e);
+    x3 = fp6_sub(x3, fp6_double(x_e_sq));
+    Fp6 y3 = fp6_sub(x_e_sq, x3);
+    y3 = fp6_mul(y3, f);
+    Fp6 t3 = fp6_mul(s.y, e_sq_e);
+    y3 = fp6_sub(y3, t3);
+    Fp6 z3 = fp6_mul(s.z, e);
+    MJac o;
+    o.x = fp6_select(x3, s.x, r.inf);
+    o.y = fp6_select(y3, s.y, r.inf);
+    o.z = fp6_select(z3, s.z, r.inf);
+    if (WANT_Z4)
+        o.z4 = fp6_square(fp6_square(o.z));
+    else
+        o.z4 = s.z4;
     return o;
 }
 

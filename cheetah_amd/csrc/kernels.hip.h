@@ -19,6 +19,12 @@ struct DeviceTables {
     u64 minus_shift_256[12];     // MINUS_SHIFT_POINT_ARRAY[256] = -2^256 S
     u64 basepoint_lookup[128 * 12];  // BASEPOINT_LOOKUP: LookupTable<128> = [G .. 128 G], x|y  src/constants.rs:26-27
     u64 odd_multiples[64 * 12];      // ODD_MULTIPLES_BASEPOINT: NafLookupTable<64> = [G, 3G .. 127 G]  src/constants.rs:32-33
+    // The accumulator of the radix-16 ladders after their first window's four doublings: every such ladder
+    // starts from S and doubles four times before its first addition (src/curve/projective.rs:617-621,
+    // src/curve/jacobian.rs:603-607), so these are constants -- the reference's own representatives,
+    // computed once with the same formulas.
+    u64 shift16_proj[18];            // double_unchecked^4(ProjectivePoint::from(S)): x | y | z
+    u64 shift16_mjac[24];            // double_unchecked^4(ModifiedJacobianPoint::from(S)): x | y | z | z4
 };
 
 // ---- AoS <-> register helpers --------------------------------------------
@@ -93,15 +99,34 @@ CH_DEV void emit_point(u64* out, u8* inf, size_t i, const MJac& p) {
 // in.  Proj = ProjectivePoint (src/curve/projective.rs:400-443, :576-610), MJac =
 // ModifiedJacobianPoint (src/curve/jacobian.rs:1094-1128, :1146-1186).
 template <class ACC> struct Ladder;
+// dbl_then_add / add_after_dbl / add_last: the doubling that directly precedes an addition, that
+// addition, and the ladder's closing addition.  For MJac the pair skips the doubling's z4 product,
+// which the addition would overwrite anyway (it rebuilds z^4 from z), and the closing addition
+// skips z4 altogether: x, y, z -- everything a JacobianPoint has -- are untouched.
 template <> struct Ladder<Proj> {
     static CH_DEV Proj from_affine(const Affine& a) { return proj_from_affine(a); }
+    static CH_DEV Proj shift16(const DeviceTables* tab) { return load_proj(tab->shift16_proj); }
     static CH_DEV Proj dbl(const Proj& p) { return proj_double_unchecked(p); }
     static CH_DEV Proj add(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
+    static CH_DEV Proj dbl_then_add(const Proj& p) { return proj_double_unchecked(p); }
+    static CH_DEV Proj add_after_dbl(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
+    static CH_DEV Proj add_last(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
 };
 template <> struct Ladder<MJac> {
     static CH_DEV MJac from_affine(const Affine& a) { return mjac_from_affine(a); }
+    static CH_DEV MJac shift16(const DeviceTables* tab) {
+        MJac m;
+        m.x = load_fp6(tab->shift16_mjac);
+        m.y = load_fp6(tab->shift16_mjac + 6);
+        m.z = load_fp6(tab->shift16_mjac + 12);
+        m.z4 = load_fp6(tab->shift16_mjac + 18);
+        return m;
+    }
     static CH_DEV MJac dbl(const MJac& p) { return mjac_double_unchecked(p); }
     static CH_DEV MJac add(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked(p, q); }
+    static CH_DEV MJac dbl_then_add(const MJac& p) { return mjac_double_unchecked_stale_z4(p); }
+    static CH_DEV MJac add_after_dbl(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<true>(p, q); }
+    static CH_DEV MJac add_last(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<false>(p, q); }
 };
 
 // ---------------------------------------------------------------------------
@@ -133,6 +158,19 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
             if (i == 4) store_affine(tab->minus_shift_4, nullptr, 0, affine_from_proj(cur));
         }
         store_affine(tab->minus_shift_256, nullptr, 0, affine_from_proj(cur));
+    } else if (t == 33) {
+        const Affine s = load_affine(shift_xy);
+        Proj p = proj_from_affine(s);
+        MJac m = mjac_from_affine(s);
+        for (int i = 0; i < 4; i++) {
+            p = proj_double_unchecked(p);
+            m = mjac_double_unchecked(m);
+        }
+        store_proj(tab->shift16_proj, nullptr, 0, p);
+        store_fp6_canonical(tab->shift16_mjac, m.x);
+        store_fp6_canonical(tab->shift16_mjac + 6, m.y);
+        store_fp6_canonical(tab->shift16_mjac + 12, m.z);
+        store_fp6_canonical(tab->shift16_mjac + 18, m.z4);
     } else if (t >= 64) {
         const bool odd = t >= 192;
         const int m = odd ? 2 * (t - 192) + 1 : t - 63;  // multiplier, by left-to-right double-and-add with the complete formulas
@@ -438,10 +476,11 @@ __global__ void __launch_bounds__(BLOCK, 2) k_mul_by_generator_lookup(const Devi
         __syncthreads();
         MJac acc = mjac_from_affine(shift);
         for (int j = 31; j >= 0; j--) {
-            for (int r = 0; r < 8; r++) acc = mjac_double_unchecked(acc);
-            acc = mjac_add_mixed_unchecked(acc, lds_lookup128(s_tab, s_digits[j * BLOCK + t]));
+            for (int r = 0; r < 7; r++) acc = mjac_double_unchecked(acc);
+            acc = Ladder<MJac>::dbl_then_add(acc);
+            acc = Ladder<MJac>::add_after_dbl(acc, lds_lookup128(s_tab, s_digits[j * BLOCK + t]));
         }
-        acc = mjac_add_mixed_unchecked(acc, mshift);
+        acc = Ladder<MJac>::add_last(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
 }
@@ -539,6 +578,36 @@ CH_DEV Proj load_input_point(const u64* pts, size_t i) {
     return load_proj(pts + 18 * i);
 }
 
+// Variable-time lookup (LookupTable::get_point_vartime, src/lookup.rs:107-126): entry |d| by index.
+CH_DEV Affine index_lookup(const u64* s_tab, u32 ident, int d, int t) {
+    const int neg = d < 0;
+    const int dabs = neg ? -d : d;
+    Affine r = affine_identity();
+    if (dabs != 0) {
+        r.x = sc_load(s_tab, dabs - 1, 0, t, 12);
+        r.y = sc_load(s_tab, dabs - 1, 6, t, 12);
+        r.inf = (ident >> (dabs - 1)) & 1;
+    }
+    return affine_cond_neg(r, neg);
+}
+
+// The radix-16 ladder of multiply (src/curve/projective.rs:617-624, src/curve/jacobian.rs:603-610): from S,
+// 64 x (four doublings, add the window's table entry), then - 2^256 S.  Window 63's four doublings of S
+// are the constant shift16.  DIRECT: look the entry up by index (variable time) instead of scanning.
+template <class ACC, bool DIRECT>
+CH_DEV ACC ladder_radix16(const DeviceTables* tab, const u64* s_tab, int n_entries, u32 ident, const i8* s_digits, int t,
+                          const Affine& mshift) {
+    int d = s_digits[63 * BLOCK + t];
+    ACC acc = Ladder<ACC>::add(Ladder<ACC>::shift16(tab), DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
+    for (int j = 62; j >= 0; j--) {
+        for (int r = 0; r < 3; r++) acc = Ladder<ACC>::dbl(acc);
+        acc = Ladder<ACC>::dbl_then_add(acc);
+        d = s_digits[j * BLOCK + t];
+        acc = Ladder<ACC>::add_after_dbl(acc, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
+    }
+    return Ladder<ACC>::add_last(acc, mshift);
+}
+
 // ProjectivePoint::multiply (ACC = Proj, src/curve/projective.rs:614-625) and
 // JacobianPoint::multiply / AffinePoint::multiply (ACC = MJac,
 // src/curve/jacobian.rs:599-611, src/curve/affine.rs:373-375): same loop, the
@@ -552,7 +621,6 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __
     u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
     u64* s_z = s_tab + (size_t)16 * 12 * BLOCK;
     u64* s_prefix = s_z + (size_t)16 * 6 * BLOCK;
-    const Affine shift = load_affine(tab->shift);
     const Affine mshift = load_affine(tab->minus_shift_256);
     const size_t nround = (n + BLOCK - 1) / BLOCK;
     for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
@@ -570,12 +638,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __
         const int n_entries = __any(wide) ? 16 : 8;
         const Proj p = load_input_point<IN_FORM>(pts, ii);
         const u32 ident = build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
-        ACC acc = Ladder<ACC>::from_affine(shift);
-        for (int j = 63; j >= 0; j--) {
-            for (int r = 0; r < 4; r++) acc = Ladder<ACC>::dbl(acc);
-            acc = Ladder<ACC>::add(acc, scan_lookup(s_tab, n_entries, ident, s_digits[j * BLOCK + t], t));
-        }
-        acc = Ladder<ACC>::add(acc, mshift);
+        const ACC acc = ladder_radix16<ACC, false>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
 }
@@ -604,10 +667,26 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
         const size_t ii = active ? i : n - 1;
         u64 k[4];
         load_scalar(scalars, uniform_scalar ? 0 : ii, k);  // uniform: is_torsion_free / clear_cofactor (one fixed scalar)
+        // AFFINE results do not depend on the ladder: for scalars below 2^255 (every canonical one) the NAF
+        // ladder and the radix-16 ladder give the same point, and a wave whose lanes all stay in step on
+        // the fixed windows is faster than one whose lanes diverge on their NAF digits.  So such a wave
+        // runs the fixed-window ladder with indexed lookups.  A scalar with bit 255 set sends its wave
+        // down the reference's NAF ladder (whose recoding drops the final carry there, src/scalar.rs:585-643);
+        // the (X, Y, Z) outputs and the one-scalar launches always take it.
+        const bool fixed_windows = OUT_FORM == 0 && !uniform_scalar && !__any((int)(k[3] >> 63));
         __syncthreads();
-        recode_wnaf(k, 5, s_naf, t);
+        if (fixed_windows)
+            recode_radix16(k, s_naf, t);
+        else
+            recode_wnaf(k, 5, s_naf, t);
         __syncthreads();
         const Proj p = load_input_point<IN_FORM>(pts, ii);
+        if (fixed_windows) {
+            const u32 ident8 = build_table<false>(p, 8, s_tab, s_z, s_prefix, t);  // top digit <= 7 below 2^255
+            const ACC r16 = ladder_radix16<ACC, true>(tab, s_tab, 8, ident8, s_naf, t, mshift);
+            if (active) emit_point<OUT_FORM>(out, inf, i, r16);
+            continue;
+        }
         const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
         ACC acc = Ladder<ACC>::from_affine(shift);
         // Every lane runs ITS OWN reference sequence (256 doublings, an addition after
@@ -675,7 +754,6 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_ct(const DeviceTable
     u64* s_prefix = s_z + ManyScratch::ZP;
     u32* s_ident = reinterpret_cast<u32*>(s_prefix + ManyScratch::ZP);
     i8* s_dig = reinterpret_cast<i8*>(s_prefix + ManyScratch::ZP + (size_t)m * BLOCK);
-    const Affine shift = load_affine(tab->shift);
     const Affine mshift = load_affine(tab->minus_shift_256);
     const size_t nround = (n_groups + BLOCK - 1) / BLOCK;
     for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
@@ -694,14 +772,19 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_ct(const DeviceTable
             const Proj p = load_input_point<IN_FORM>(pts, gg * m + j);
             s_ident[j * BLOCK + t] = build_table<false>(p, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
         }
-        ACC acc = Ladder<ACC>::from_affine(shift);
+        ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S
         for (int w = 63; w >= 0; w--) {
-            for (int r = 0; r < 4; r++) acc = Ladder<ACC>::dbl(acc);
-            for (int j = 0; j < m; j++)
-                acc = Ladder<ACC>::add(acc, scan_lookup(s_tabs + (size_t)j * ManyScratch::TAB, n_entries, s_ident[j * BLOCK + t],
-                                                        s_dig[((size_t)j * 256 + w) * BLOCK + t], t));
+            if (w < 63) {
+                for (int r = 0; r < 3; r++) acc = Ladder<ACC>::dbl(acc);
+                acc = Ladder<ACC>::dbl_then_add(acc);
+            }
+            for (int j = 0; j < m; j++) {
+                const Affine q = scan_lookup(s_tabs + (size_t)j * ManyScratch::TAB, n_entries, s_ident[j * BLOCK + t],
+                                             s_dig[((size_t)j * 256 + w) * BLOCK + t], t);
+                acc = (j == 0 && w < 63) ? Ladder<ACC>::add_after_dbl(acc, q) : Ladder<ACC>::add(acc, q);
+            }
         }
-        acc = Ladder<ACC>::add(acc, mshift);
+        acc = Ladder<ACC>::add_last(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, g, acc);
     }
 }
