@@ -176,24 +176,24 @@ CH_DEV Proj proj_add_mixed_unchecked(const Proj& s, const Affine& r) {
 }
 
 // src/curve/jacobian.rs:1094-1128
+// The same field elements are reached with fewer small-constant products: with y2 = 2y,
+// 4 y^2 = y2^2, 16 y^4 = (y2^2)^2 = 2c, z3 = y2 z, and c = 8 y^4 is half of 2c.
 CH_DEV MJac mjac_double_unchecked(const MJac& s) {
     Fp6 x_sq = fp6_square(s.x);
-    Fp6 y_sq = fp6_square(s.y);
-    Fp6 y_sq2 = fp6_square(y_sq);
-    Fp6 a = fp6_mul_small(y_sq, 4u);
-    a = fp6_mul(a, s.x);
+    Fp6 y2 = fp6_double(s.y);
+    Fp6 y_sq4 = fp6_square(y2);        // 4 y^2
+    Fp6 c2 = fp6_square(y_sq4);        // 16 y^4 = 2c
+    Fp6 a = fp6_mul(y_sq4, s.x);       // 4 x y^2
     Fp6 b = fp6_triple(x_sq);
     b = fp6_add(b, s.z4);
-    Fp6 c = fp6_mul_small(y_sq2, 8u);
+    Fp6 c = fp6_halve(c2);             // 8 y^4
     Fp6 x3 = fp6_square(b);
     x3 = fp6_sub(x3, fp6_double(a));
     Fp6 y3 = fp6_sub(a, x3);
     y3 = fp6_mul(y3, b);
     y3 = fp6_sub(y3, c);
-    Fp6 z3 = fp6_double(s.y);
-    z3 = fp6_mul(z3, s.z);
-    Fp6 z34 = fp6_double(c);
-    z34 = fp6_mul(z34, s.z4);
+    Fp6 z3 = fp6_mul(y2, s.z);
+    Fp6 z34 = fp6_mul(c2, s.z4);
     MJac o;
     o.x = x3;
     o.y = y3;
@@ -207,20 +207,18 @@ CH_DEV MJac mjac_double_unchecked(const MJac& s) {
 // emitted (a JacobianPoint has no z4, src/curve/jacobian.rs:118-126).  x, y, z are unchanged.
 CH_DEV MJac mjac_double_unchecked_stale_z4(const MJac& s) {
     Fp6 x_sq = fp6_square(s.x);
-    Fp6 y_sq = fp6_square(s.y);
-    Fp6 y_sq2 = fp6_square(y_sq);
-    Fp6 a = fp6_mul_small(y_sq, 4u);
-    a = fp6_mul(a, s.x);
+    Fp6 y2 = fp6_double(s.y);
+    Fp6 y_sq4 = fp6_square(y2);
+    Fp6 c = fp6_halve(fp6_square(y_sq4));
+    Fp6 a = fp6_mul(y_sq4, s.x);
     Fp6 b = fp6_triple(x_sq);
     b = fp6_add(b, s.z4);
-    Fp6 c = fp6_mul_small(y_sq2, 8u);
     Fp6 x3 = fp6_square(b);
     x3 = fp6_sub(x3, fp6_double(a));
     Fp6 y3 = fp6_sub(a, x3);
     y3 = fp6_mul(y3, b);
     y3 = fp6_sub(y3, c);
-    Fp6 z3 = fp6_double(s.y);
-    z3 = fp6_mul(z3, s.z);
+    Fp6 z3 = fp6_mul(y2, s.z);
     MJac o;
     o.x = x3;
     o.y = y3;

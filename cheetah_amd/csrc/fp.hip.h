@@ -51,6 +51,90 @@ CH_DEV u64 fp_sub(u64 a, u64 b) {
 CH_DEV u64 fp_neg(u64 a) { return fp_sub(0ull, a); }     // src/fp.rs:172-174
 CH_DEV u64 fp_double(u64 a) { return fp_add(a, a); }     // src/fp.rs:145-150
 
+// Three independent a + b / a - b at once, the form the Fp6 linear operations use.
+// hipcc's code for fp_add / fp_sub re-derives each carry with a 64-bit compare (7 and 10
+// VALU instructions); here the carry masks are used directly and eps = 2^32 - 1 is applied
+// as carries (+ eps: low word - 1, high word + 1 less the low word's borrow): 6 VALU + 2 SALU
+// per element.  The three chains are interleaved stage by stage so that two VALU
+// instructions always separate the write of a carry mask from the carry-in that reads it
+// (the two wait states gfx950 needs; the compiler pads its own code with s_nop).
+#define CH_LIN3_OPERANDS                                                                                             \
+    : [l0] "+v"(l0), [h0] "+v"(h0), [l1] "+v"(l1), [h1] "+v"(h1), [l2] "+v"(l2), [h2] "+v"(h2), [s0] "=&s"(s0),      \
+      [u0] "=&s"(u0), [s1] "=&s"(s1), [u1] "=&s"(u1), [s2] "=&s"(s2), [u2] "=&s"(u2)                                 \
+    : [bl0] "v"(lo32(b0)), [bh0] "v"(hi32(b0)), [bl1] "v"(lo32(b1)), [bh1] "v"(hi32(b1)), [bl2] "v"(lo32(b2)),       \
+      [bh2] "v"(hi32(b2))                                                                                            \
+    : "scc"
+CH_DEV void fp_add3(u64& a0, u64& a1, u64& a2, u64 b0, u64 b1, u64 b2) {
+    u32 l0 = lo32(a0), h0 = hi32(a0), l1 = lo32(a1), h1 = hi32(a1), l2 = lo32(a2), h2 = hi32(a2);
+    u64 s0, u0, s1, u1, s2, u2;
+    asm("v_add_co_u32 %[l0], %[s0], %[l0], %[bl0]\n\t"
+        "v_add_co_u32 %[l1], %[s1], %[l1], %[bl1]\n\t"
+        "v_add_co_u32 %[l2], %[s2], %[l2], %[bl2]\n\t"
+        "v_addc_co_u32 %[h0], %[s0], %[h0], %[bh0], %[s0]\n\t"
+        "v_addc_co_u32 %[h1], %[s1], %[h1], %[bh1], %[s1]\n\t"
+        "v_addc_co_u32 %[h2], %[s2], %[h2], %[bh2], %[s2]\n\t"
+        // + c * eps: low word - c (borrow k in u), high word + (c & ~k) (carry c2 in u)
+        "v_subbrev_co_u32 %[l0], %[u0], 0, %[l0], %[s0]\n\t"
+        "v_subbrev_co_u32 %[l1], %[u1], 0, %[l1], %[s1]\n\t"
+        "v_subbrev_co_u32 %[l2], %[u2], 0, %[l2], %[s2]\n\t"
+        "s_andn2_b64 %[s0], %[s0], %[u0]\n\t"
+        "s_andn2_b64 %[s1], %[s1], %[u1]\n\t"
+        "s_andn2_b64 %[s2], %[s2], %[u2]\n\t"
+        "v_addc_co_u32 %[h0], %[u0], %[h0], 0, %[s0]\n\t"
+        "v_addc_co_u32 %[h1], %[u1], %[h1], 0, %[s1]\n\t"
+        "v_addc_co_u32 %[h2], %[u2], %[h2], 0, %[s2]\n\t"
+        // + c2 * eps (a third carry cannot occur)
+        "v_subbrev_co_u32 %[l0], %[s0], 0, %[l0], %[u0]\n\t"
+        "v_subbrev_co_u32 %[l1], %[s1], 0, %[l1], %[u1]\n\t"
+        "v_subbrev_co_u32 %[l2], %[s2], 0, %[l2], %[u2]\n\t"
+        "s_andn2_b64 %[u0], %[u0], %[s0]\n\t"
+        "s_andn2_b64 %[u1], %[u1], %[s1]\n\t"
+        "s_andn2_b64 %[u2], %[u2], %[s2]\n\t"
+        "v_addc_co_u32 %[h0], %[s0], %[h0], 0, %[u0]\n\t"
+        "v_addc_co_u32 %[h1], %[s1], %[h1], 0, %[u1]\n\t"
+        "v_addc_co_u32 %[h2], %[s2], %[h2], 0, %[u2]" CH_LIN3_OPERANDS);
+    a0 = mk64(l0, h0);
+    a1 = mk64(l1, h1);
+    a2 = mk64(l2, h2);
+}
+CH_DEV void fp_sub3(u64& a0, u64& a1, u64& a2, u64 b0, u64 b1, u64 b2) {
+    u32 l0 = lo32(a0), h0 = hi32(a0), l1 = lo32(a1), h1 = hi32(a1), l2 = lo32(a2), h2 = hi32(a2);
+    u64 s0, u0, s1, u1, s2, u2;
+    asm("v_sub_co_u32 %[l0], %[s0], %[l0], %[bl0]\n\t"
+        "v_sub_co_u32 %[l1], %[s1], %[l1], %[bl1]\n\t"
+        "v_sub_co_u32 %[l2], %[s2], %[l2], %[bl2]\n\t"
+        "v_subb_co_u32 %[h0], %[s0], %[h0], %[bh0], %[s0]\n\t"
+        "v_subb_co_u32 %[h1], %[s1], %[h1], %[bh1], %[s1]\n\t"
+        "v_subb_co_u32 %[h2], %[s2], %[h2], %[bh2], %[s2]\n\t"
+        // - c * eps: low word + c (carry k in u), high word - (c & ~k) (borrow c2 in u)
+        "v_addc_co_u32 %[l0], %[u0], %[l0], 0, %[s0]\n\t"
+        "v_addc_co_u32 %[l1], %[u1], %[l1], 0, %[s1]\n\t"
+        "v_addc_co_u32 %[l2], %[u2], %[l2], 0, %[s2]\n\t"
+        "s_andn2_b64 %[s0], %[s0], %[u0]\n\t"
+        "s_andn2_b64 %[s1], %[s1], %[u1]\n\t"
+        "s_andn2_b64 %[s2], %[s2], %[u2]\n\t"
+        "v_subbrev_co_u32 %[h0], %[u0], 0, %[h0], %[s0]\n\t"
+        "v_subbrev_co_u32 %[h1], %[u1], 0, %[h1], %[s1]\n\t"
+        "v_subbrev_co_u32 %[h2], %[u2], 0, %[h2], %[s2]\n\t"
+        // - c2 * eps (a third borrow cannot occur)
+        "v_addc_co_u32 %[l0], %[s0], %[l0], 0, %[u0]\n\t"
+        "v_addc_co_u32 %[l1], %[s1], %[l1], 0, %[u1]\n\t"
+        "v_addc_co_u32 %[l2], %[s2], %[l2], 0, %[u2]\n\t"
+        "s_andn2_b64 %[u0], %[u0], %[s0]\n\t"
+        "s_andn2_b64 %[u1], %[u1], %[s1]\n\t"
+        "s_andn2_b64 %[u2], %[u2], %[s2]\n\t"
+        "v_subbrev_co_u32 %[h0], %[s0], 0, %[h0], %[u0]\n\t"
+        "v_subbrev_co_u32 %[h1], %[s1], 0, %[h1], %[u1]\n\t"
+        "v_subbrev_co_u32 %[h2], %[s2], 0, %[h2], %[u2]" CH_LIN3_OPERANDS);
+    a0 = mk64(l0, h0);
+    a1 = mk64(l1, h1);
+    a2 = mk64(l2, h2);
+}
+#undef CH_LIN3_OPERANDS
+
+// a / 2 mod p: (a >> 1) + (a odd ? (p + 1) / 2 : 0); the sum stays below 2^64.
+CH_DEV u64 fp_halve(u64 a) { return (a >> 1) + ((a & 1ull) ? 0x7fffffff80000001ull : 0ull); }
+
 // Canonical representative in [0, p).               (src/fp.rs:125-127)
 CH_DEV u64 fp_canonical(u64 a) { return a >= FP_P ? a - FP_P : a; }
 CH_DEV bool fp_is_zero(u64 a) { return a == 0ull || a == FP_P; }
@@ -126,18 +210,34 @@ struct Acc3 {
         w2 = __builtin_addc(w2, t0, 0u, &c);
         w3 = __builtin_addc(w3, 0u, c, &c);
         w4 += c;
-        // R = (w1:w0) + eps * w2, eps * w2 = (w2 << 32) - w2; carry k is worth 2^64 = eps
-        u32 b, k;
-        const u32 elo = __builtin_subc(0u, w2, 0u, &b);
-        const u32 ehi = w2 - b;
-        const u32 r0 = __builtin_addc(w0, elo, 0u, &k);
-        const u32 r1 = __builtin_addc(w1, ehi, k, &k);
-        // Q = R - (w3 + 2^32 w4); borrow b is worth -2^64 = -eps
-        const u32 q0 = __builtin_subc(r0, w3, 0u, &b);
-        const u32 q1 = __builtin_subc(r1, w4, b, &b);
-        // net correction (k - b) * eps; neither case can wrap
-        const u64 corr = (k && !b) ? FP_EPS : ((b && !k) ? (0ull - FP_EPS) : 0ull);
-        return mk64(q0, q1) + corr;
+        // R = (w1:w0) + eps * w2 in ONE v_mad_u64_u32 (eps = 0xffffffff is the inline constant -1);
+        // its carry k (lane mask sk) is worth 2^64 = eps.
+        u64 r = mk64(w0, w1), sk;
+        asm("v_mad_u64_u32 %[r], %[sk], %[w2], -1, %[r]" : [r] "+v"(r), [sk] "=s"(sk) : [w2] "v"(w2));
+        // Q = R - (w3 + 2^32 w4); its borrow b (mask sb) is worth -2^64 = -eps.  Net correction
+        // (k - b) * eps; neither case can wrap.  + eps = + 2^32 - 1 and
+        // - eps = - 2^32 + 1 are applied as carries: the low word gets -1 on the lanes of
+        // sp = k & ~b and +1 on those of sn = b & ~k, the high word the opposite, each less the
+        // carry / borrow that came out of the low word.  (SALU reads of a VALU-written mask are
+        // interlocked by the hardware; a VALU carry-in read needs two wait states after the VALU
+        // write, hence the one s_nop.)
+        u32 q0, q1;
+        u64 sb, sp, sn, sa;
+        asm("v_sub_co_u32 %[q0], %[sb], %[r0], %[w3]\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32 %[q1], %[sb], %[r1], %[w4], %[sb]\n\t"
+            "s_andn2_b64 %[sp], %[sk], %[sb]\n\t"
+            "s_andn2_b64 %[sn], %[sb], %[sk]\n\t"
+            "v_subbrev_co_u32 %[q0], %[sa], 0, %[q0], %[sp]\n\t"
+            "v_addc_co_u32 %[q0], %[sb], %[q0], 0, %[sn]\n\t"
+            "s_andn2_b64 %[sp], %[sp], %[sa]\n\t"
+            "s_andn2_b64 %[sn], %[sn], %[sb]\n\t"
+            "v_addc_co_u32 %[q1], %[sa], %[q1], 0, %[sp]\n\t"
+            "v_subbrev_co_u32 %[q1], %[sa], 0, %[q1], %[sn]"
+            : [q0] "=&v"(q0), [q1] "=&v"(q1), [sb] "=&s"(sb), [sp] "=&s"(sp), [sn] "=&s"(sn), [sa] "=&s"(sa)
+            : [r0] "v"(lo32(r)), [r1] "v"(hi32(r)), [w3] "v"(w3), [w4] "v"(w4), [sk] "s"(sk)
+            : "scc");
+        return mk64(q0, q1);
     }
 };
 

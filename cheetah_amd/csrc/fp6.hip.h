@@ -52,10 +52,21 @@ CH_DEV Fp6 fp6_one() {
             r.c[i] = OP(a.c[i]);                         \
         return r;                                        \
     }
-CH_FP6_COEFFWISE2(fp6_add, fp_add)          // src/fp6.rs:994-1003
-CH_FP6_COEFFWISE2(fp6_sub, fp_sub)          // src/fp6.rs:1007-1016
+CH_DEV Fp6 fp6_add(const Fp6& a, const Fp6& b) {  // src/fp6.rs:994-1003
+    Fp6 r = a;
+    fp_add3(r.c[0], r.c[1], r.c[2], b.c[0], b.c[1], b.c[2]);
+    fp_add3(r.c[3], r.c[4], r.c[5], b.c[3], b.c[4], b.c[5]);
+    return r;
+}
+CH_DEV Fp6 fp6_sub(const Fp6& a, const Fp6& b) {  // src/fp6.rs:1007-1016
+    Fp6 r = a;
+    fp_sub3(r.c[0], r.c[1], r.c[2], b.c[0], b.c[1], b.c[2]);
+    fp_sub3(r.c[3], r.c[4], r.c[5], b.c[3], b.c[4], b.c[5]);
+    return r;
+}
 CH_FP6_COEFFWISE1(fp6_neg, fp_neg)          // src/fp6.rs:1020-1029
-CH_FP6_COEFFWISE1(fp6_double, fp_double)    // src/fp6.rs:968-977
+CH_DEV Fp6 fp6_double(const Fp6& a) { return fp6_add(a, a); }  // src/fp6.rs:968-977
+CH_FP6_COEFFWISE1(fp6_halve, fp_halve)      // a / 2 (no counterpart: see mjac_double_unchecked)
 CH_FP6_COEFFWISE1(fp6_triple, fp_triple)    // src/fp6.rs:981-990
 CH_FP6_COEFFWISE1(fp6_canonical, fp_canonical)  // src/fp6.rs:373-382
 

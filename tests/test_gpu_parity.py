@@ -98,6 +98,49 @@ def test_fp6_device_functions(eng, ora):
             assert (got[i] == want).all(), (name, i)
 
 
+CARRY_EDGE = sorted(set(EDGE_FP + [
+    2**64 - 2, 2**64 - 2**32, 2**64 - 2**32 - 1, 2**64 - 2**32 + 2, 2**33 - 2, 2**33 - 1, 2**33, 2**32 - 2,
+    0x00000001FFFFFFFF, 0xFFFFFFFE00000001, 0xFFFFFFFE00000002, 0xFFFFFFFEFFFFFFFF, 0x7FFFFFFF80000000,
+    0x7FFFFFFF80000001, 0x8000000000000001, 0x00000000FFFFFFFE, 0xFFFFFFFF00000002, 0xFFFFFFFFFFFFFFFE - 2**32]))
+
+
+def test_fp6_linear_and_mul_carry_edges(eng):
+    """Every pair of carry-edge limbs through the carry-mask forms of Fp6 add / sub (fp_add3 / fp_sub3: sums and
+    differences whose low word ends at 0 or 2^32 - 1, double folds) and all-edge operands through the
+    accumulate-and-reduce of Fp6 mul / square, against Python integers."""
+    E = CARRY_EDGE
+    pairs = [(x, y) for x in E for y in E]
+    while len(pairs) % 6:
+        pairs.append((E[0], E[-1]))
+    a = np.array([p[0] for p in pairs], np.uint64).reshape(-1, 6)
+    b = np.array([p[1] for p in pairs], np.uint64).reshape(-1, 6)
+    A, B = dev(a), dev(b)
+    ai = [[int(v) for v in r] for r in a]
+    bi = [[int(v) for v in r] for r in b]
+    got = host(eng.debug_op(16, A, B, 6))
+    assert [[int(g) % P for g in r] for r in got] == [[(x + y) % P for x, y in zip(ra, rb)] for ra, rb in zip(ai, bi)]
+    got = host(eng.debug_op(17, A, B, 6))
+    assert [[int(g) % P for g in r] for r in got] == [[(x - y) % P for x, y in zip(ra, rb)] for ra, rb in zip(ai, bi)]
+
+    def mul_model(x, y):
+        c = [0] * 11
+        for i in range(6):
+            for j in range(6):
+                c[i + j] += x[i] * y[j]
+        return [(c[k] + 7 * (c[k + 6] if k < 5 else 0)) % P for k in range(6)]
+
+    rng = np.random.default_rng(77)
+    n = 6000
+    x = np.array(E, np.uint64)[rng.integers(0, len(E), (n, 6))]
+    y = np.array(E, np.uint64)[rng.integers(0, len(E), (n, 6))]
+    x[0], y[0] = [2**64 - 1] * 6, [2**64 - 1] * 6
+    x[1], y[1] = [2**64 - 1] * 6, [P - 1] * 6
+    got = eng.fp6_mul_batch(x, y)
+    assert [list(map(int, r)) for r in got] == [mul_model(list(map(int, r)), list(map(int, s))) for r, s in zip(x, y)]
+    got = eng.fp6_square_batch(x)
+    assert [list(map(int, r)) for r in got] == [mul_model(list(map(int, r)), list(map(int, r))) for r in x]
+
+
 def _random_points(ora, seed, n, form):
     """k_i * G as affine, projective or Jacobian (the latter two scaled by a random lambda)."""
     sc = synth.scalars(seed, n)
