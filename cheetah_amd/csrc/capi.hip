@@ -237,7 +237,7 @@ static int32_t batch_normalize_dev(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8
     if (!aligned16(xyz) || !aligned16(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "point arrays must be 16-byte aligned");
     constexpr int CHUNK = 8;
     size_t nchunks = (n + CHUNK - 1) / CHUNK;
-    int grid = lane_grid(ctx, nchunks, 2);
+    int grid = lane_grid(ctx, nchunks, CH_BN_WAVES);
     hipLaunchKernelGGL((k_batch_normalize<JAC, CHUNK>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
@@ -271,7 +271,7 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
     if (n == 0) return CHEETAH_OK;
     if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
-    int grid = lane_grid(ctx, n, 2);
+    int grid = lane_grid(ctx, n, CH_GEN_WAVES);
     const size_t out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
     const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH * 4;  // bounded launches, as in multiply_dev
     for (size_t off = 0; off < n; off += per_launch) {
@@ -298,8 +298,12 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
     if (n == 0) return CHEETAH_OK;
     if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
-    int grid = lane_grid(ctx, n, 2);
-    if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
+    // multiply_vartime with AFFINE results: the fixed-window ladder with indexed lookups (k_multiply_ct<..., DIRECT>)
+    // for every wave whose scalars are all below 2^255, then the reference's NAF ladder for the remaining waves.
+    const bool direct = VARTIME && out_form == CHEETAH_AFFINE;
+    const int grid_vt = lane_grid(ctx, n, CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
+    const int grid = (VARTIME && !direct) ? grid_vt : grid_ct;
+    if (int32_t rc = ensure_scratch(ctx, (size_t)(grid_vt > grid_ct ? grid_vt : grid_ct) * LaneScratch::WORDS_PER_BLOCK)) return rc;
     // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (~25 ms of
     // work).  The workgroups are persistent within a launch and fill every CU, so a kernel
     // on another stream (the RCCL all-gather of the previous chunk) can only get CU slots
@@ -314,12 +318,17 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         u8* inf_o = inf ? inf + off : nullptr;
 #define LAUNCH(KERN, A, I, O)                                                                                                   \
     do {                                                                                                                       \
-        if (VARTIME)                                                                                                           \
-            hipLaunchKernelGGL((k_multiply_vartime<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o, \
-                               out_o, inf_o, cnt, ctx->scratch, 0);                                                            \
+        if constexpr (VARTIME && O == 0) {                                                                                             \
+            hipLaunchKernelGGL((k_multiply_ct<A, I, O, true>), dim3(grid_ct), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,  \
+                               sc_o, out_o, inf_o, cnt, ctx->scratch);                                                         \
+            hipLaunchKernelGGL((k_multiply_vartime<A, I, O, true>), dim3(grid_vt), dim3(BLOCK), 0, ctx->stream, ctx->tables,    \
+                               pts_o, sc_o, out_o, inf_o, cnt, ctx->scratch, 0);                                               \
+        } else if constexpr (VARTIME)                                                                                              \
+            hipLaunchKernelGGL((k_multiply_vartime<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,      \
+                               pts_o, sc_o, out_o, inf_o, cnt, ctx->scratch, 0);                                               \
         else                                                                                                                   \
-            hipLaunchKernelGGL((k_multiply_ct<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o,      \
-                               out_o, inf_o, cnt, ctx->scratch);                                                               \
+            hipLaunchKernelGGL((k_multiply_ct<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,    \
+                               sc_o, out_o, inf_o, cnt, ctx->scratch);                                                         \
     } while (0)
 #define DISPATCH(KERN)                                         \
     switch (in_form * 3 + out_form) {                          \
@@ -563,7 +572,7 @@ extern "C" int32_t cheetah_multiply_double_with_basepoint_vartime_batch_dev(chee
 // same NAF, so the wave never diverges).  out_form 3 = identity flag only.
 static int32_t fixed_scalar_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* dev_scalar, u64* out, u8* inf, size_t n,
                                 int out_form) {
-    int grid = lane_grid(ctx, n, 2);
+    int grid = lane_grid(ctx, n, CH_VT_WAVES);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
     const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
     const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;

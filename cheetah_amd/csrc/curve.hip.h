@@ -175,60 +175,48 @@ CH_DEV Proj proj_add_mixed_unchecked(const Proj& s, const Affine& r) {
     return o;
 }
 
-// src/curve/jacobian.rs:1094-1128
+// ModifiedJacobianPoint::double_unchecked (src/curve/jacobian.rs:1094-1128).
 // The same field elements are reached with fewer small-constant products: with y2 = 2y,
-// 4 y^2 = y2^2, 16 y^4 = (y2^2)^2 = 2c, z3 = y2 z, and c = 8 y^4 is half of 2c.
-CH_DEV MJac mjac_double_unchecked(const MJac& s) {
-    Fp6 x_sq = fp6_square(s.x);
+// 4 y^2 = y2^2, 16 y^4 = (y2^2)^2 = 2c, z3 = y2 z, and c = 8 y^4 is half of 2c.  The products are
+// ordered so that at most six Fp6 values are live at once (the ladder kernels run at 168 VGPRs).
+template <bool WANT_Z4>
+CH_DEV MJac mjac_double_impl(const MJac& s) {
+    MJac o;
     Fp6 y2 = fp6_double(s.y);
+    o.z = fp6_mul(y2, s.z);            // z3 = 2 y z
     Fp6 y_sq4 = fp6_square(y2);        // 4 y^2
     Fp6 c2 = fp6_square(y_sq4);        // 16 y^4 = 2c
-    Fp6 a = fp6_mul(y_sq4, s.x);       // 4 x y^2
-    Fp6 b = fp6_triple(x_sq);
-    b = fp6_add(b, s.z4);
+    Fp6 b = fp6_triple(fp6_square(s.x));
+    b = fp6_add(b, s.z4);              // 3 x^2 + z^4
+    if (WANT_Z4)
+        o.z4 = fp6_mul(c2, s.z4);      // 2c z^4
+    else
+        o.z4 = s.z4;
     Fp6 c = fp6_halve(c2);             // 8 y^4
-    Fp6 x3 = fp6_square(b);
-    x3 = fp6_sub(x3, fp6_double(a));
-    Fp6 y3 = fp6_sub(a, x3);
-    y3 = fp6_mul(y3, b);
-    y3 = fp6_sub(y3, c);
-    Fp6 z3 = fp6_mul(y2, s.z);
-    Fp6 z34 = fp6_mul(c2, s.z4);
-    MJac o;
-    o.x = x3;
-    o.y = y3;
-    o.z = z3;
-    o.z4 = z34;
+    Fp6 a = fp6_mul(y_sq4, s.x);       // 4 x y^2
+    o.x = fp6_square(b);
+    o.x = fp6_sub(o.x, fp6_double(a));
+    o.y = fp6_sub(a, o.x);
+    o.y = fp6_mul(o.y, b);
+    o.y = fp6_sub(o.y, c);
     return o;
 }
+// src/curve/jacobian.rs:1094-1128
+CH_DEV MJac mjac_double_unchecked(const MJac& s) { return mjac_double_impl<true>(s); }
 
 // The same doubling without its last product: z4 is left stale.  Only valid when the next
 // operation is mjac_add_mixed_unchecked_fresh_z4 (which rebuilds z^4 from z) or the point is
 // emitted (a JacobianPoint has no z4, src/curve/jacobian.rs:118-126).  x, y, z are unchanged.
-CH_DEV MJac mjac_double_unchecked_stale_z4(const MJac& s) {
-    Fp6 x_sq = fp6_square(s.x);
-    Fp6 y2 = fp6_double(s.y);
-    Fp6 y_sq4 = fp6_square(y2);
-    Fp6 c = fp6_halve(fp6_square(y_sq4));
-    Fp6 a = fp6_mul(y_sq4, s.x);
-    Fp6 b = fp6_triple(x_sq);
-    b = fp6_add(b, s.z4);
-    Fp6 x3 = fp6_square(b);
-    x3 = fp6_sub(x3, fp6_double(a));
-    Fp6 y3 = fp6_sub(a, x3);
-    y3 = fp6_mul(y3, b);
-    y3 = fp6_sub(y3, c);
-    Fp6 z3 = fp6_mul(y2, s.z);
-    MJac o;
-    o.x = x3;
-    o.y = y3;
-    o.z = z3;
-    o.z4 = s.z4;
-    return o;
-}
+CH_DEV MJac mjac_double_unchecked_stale_z4(const MJac& s) { return mjac_double_impl<false>(s); }
 
-// src/curve/jacobian.rs:1146-1186
-CH_DEV MJac mjac_add_mixed_unchecked(const MJac& s, const Affine& r) {
+// src/curve/jacobian.rs:1146-1186.  FRESH_Z4: the accumulator's z4 is stale (see above) and z^4 is
+// rebuilt from the z that is returned, so it is right for the identity operand too (the reference
+// returns self there, whose z4 = z^4 by construction); otherwise the reference's own selection.
+// WANT_Z4 = false: the result is emitted, z4 is not needed.  Same products as the reference, ordered
+// for short live ranges; each output is selected as soon as it is complete.
+template <bool FRESH_Z4, bool WANT_Z4>
+CH_DEV MJac mjac_add_mixed_impl(const MJac& s, const Affine& r) {
+    MJac o;
     Fp6 z1_sq = fp6_square(s.z);
     Fp6 b = fp6_mul(r.x, z1_sq);
     Fp6 d = fp6_mul(s.z, z1_sq);
@@ -236,57 +224,35 @@ CH_DEV MJac mjac_add_mixed_unchecked(const MJac& s, const Affine& r) {
     Fp6 e = fp6_sub(b, s.x);
     Fp6 f = fp6_sub(d, s.y);
     Fp6 e_sq = fp6_square(e);
+    Fp6 z3 = fp6_mul(s.z, e);
+    o.z = fp6_select(z3, s.z, r.inf);
+    if (!FRESH_Z4) {
+        Fp6 z34 = fp6_square(fp6_square(z3));
+        o.z4 = fp6_select(z34, s.z4, r.inf);
+    }
     Fp6 e_sq_e = fp6_mul(e, e_sq);
     Fp6 x_e_sq = fp6_mul(s.x, e_sq);
     Fp6 x3 = fp6_square(f);
     x3 = fp6_sub(x3, e_sq_e);
     x3 = fp6_sub(x3, fp6_double(x_e_sq));
     Fp6 y3 = fp6_sub(x_e_sq, x3);
-    y3 = fp6_mul(y3, f);
-    Fp6 t3 = fp6_mul(s.y, e_sq_e);
-    y3 = fp6_sub(y3, t3);
-    Fp6 z3 = fp6_mul(s.z, e);
-    Fp6 z34 = fp6_square(z3);
-    z34 = fp6_square(z34);
-    MJac o;
     o.x = fp6_select(x3, s.x, r.inf);
+    Fp6 t3 = fp6_mul(s.y, e_sq_e);
+    y3 = fp6_mul(y3, f);
+    y3 = fp6_sub(y3, t3);
     o.y = fp6_select(y3, s.y, r.inf);
-    o.z = fp6_select(z3, s.z, r.inf);
-    o.z4 = fp6_select(z34, s.z4, r.inf);
+    if (FRESH_Z4) {
+        if (WANT_Z4)
+            o.z4 = fp6_square(fp6_square(o.z));
+        else
+            o.z4 = s.z4;
+    }
     return o;
 }
-
-// The same addition for an accumulator whose z4 is stale: z^4 is rebuilt from the z that is
-// returned, so it is right for the identity operand too (the reference returns self there,
-// whose z4 = z^4 by construction).  WANT_Z4 = false: the result is emitted, z4 is not needed.
+CH_DEV MJac mjac_add_mixed_unchecked(const MJac& s, const Affine& r) { return mjac_add_mixed_impl<false, true>(s, r); }
 template <bool WANT_Z4>
 CH_DEV MJac mjac_add_mixed_unchecked_fresh_z4(const MJac& s, const Affine& r) {
-    Fp6 z1_sq = fp6_square(s.z);
-    Fp6 b = fp6_mul(r.x, z1_sq);
-    Fp6 d = fp6_mul(s.z, z1_sq);
-    d = fp6_mul(d, r.y);
-    Fp6 e = fp6_sub(b, s.x);
-    Fp6 f = fp6_sub(d, s.y);
-    Fp6 e_sq = fp6_square(e);
-    Fp6 e_sq_e = fp6_mul(e, e_sq);
-    Fp6 x_e_sq = fp6_mul(s.x, e_sq);
-    Fp6 x3 = fp6_square(f);
-    x3 = fp6_sub(x3, e_sq_e);
-    x3 = fp6_sub(x3, fp6_double(x_e_sq));
-    Fp6 y3 = fp6_sub(x_e_sq, x3);
-    y3 = fp6_mul(y3, f);
-    Fp6 t3 = fp6_mul(s.y, e_sq_e);
-    y3 = fp6_sub(y3, t3);
-    Fp6 z3 = fp6_mul(s.z, e);
-    MJac o;
-    o.x = fp6_select(x3, s.x, r.inf);
-    o.y = fp6_select(y3, s.y, r.inf);
-    o.z = fp6_select(z3, s.z, r.inf);
-    if (WANT_Z4)
-        o.z4 = fp6_square(fp6_square(o.z));
-    else
-        o.z4 = s.z4;
-    return o;
+    return mjac_add_mixed_impl<true, WANT_Z4>(s, r);
 }
 
 // Single-point normalisations (one Fp6 inversion each).

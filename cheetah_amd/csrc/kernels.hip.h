@@ -9,6 +9,22 @@ typedef uint8_t u8;
 typedef int8_t i8;
 
 constexpr int BLOCK = 256;
+// Waves per SIMD (= 256-thread workgroups per CU) the kernels are compiled and launched for.
+// Measured at 2^20 / 2^24 (tools/ladder_bench.py, tools/bn_bench.py; waves 2 / 3 / 4): constant-time ladder
+// 25.6 / 27.8 / 28.4 M/s (at 128 VGPRs the window loop keeps two spill accesses, the rest are in the table
+// build), fixed base 91 / 97 / 100 M/s, batch_normalize 7.2 / 7.4 / 7.2 G/s; the NAF kernel loses at 3.
+#ifndef CH_CT_WAVES
+#define CH_CT_WAVES 4
+#endif
+#ifndef CH_VT_WAVES
+#define CH_VT_WAVES 2
+#endif
+#ifndef CH_GEN_WAVES
+#define CH_GEN_WAVES 4
+#endif
+#ifndef CH_BN_WAVES
+#define CH_BN_WAVES 3
+#endif
 
 // ---------------------------------------------------------------------------
 // Precomputed tables, built on the device at context creation.
@@ -252,7 +268,7 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
 // consecutive 144-byte records with 16-byte accesses -- each 128-byte line is
 // fetched from HBM once -- instead of one record per 1 152 bytes.
 template <int JAC, int CHUNK>
-__global__ void __launch_bounds__(BLOCK, 2) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
+__global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
                                                               u8* __restrict__ inf, size_t n) {
     const size_t tile_pts = (size_t)BLOCK * CHUNK;
     const size_t ntiles = (n + tile_pts - 1) / tile_pts;
@@ -382,7 +398,7 @@ CH_DEV Affine lds_lookup8(const u64* sub /* 8 x 12 limbs in LDS */, int d) {
 }
 
 template <int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK, 2) k_mul_by_generator(const DeviceTables* __restrict__ tab,
+__global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const DeviceTables* __restrict__ tab,
                                                             const u8* __restrict__ scalars, u64* __restrict__ out,
                                                             u8* __restrict__ inf, size_t n) {
     __shared__ u64 s_tab[32 * 8 * 12];
@@ -456,7 +472,7 @@ CH_DEV Affine lds_lookup128(const u64* tabl /* 128 x 12 limbs in LDS */, int d) 
 }
 
 template <int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK, 2) k_mul_by_generator_lookup(const DeviceTables* __restrict__ tab,
+__global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator_lookup(const DeviceTables* __restrict__ tab,
                                                                    const u8* __restrict__ scalars, u64* __restrict__ out,
                                                                    u8* __restrict__ inf, size_t n) {
     __shared__ u64 s_tab[128 * 12];
@@ -612,8 +628,13 @@ CH_DEV ACC ladder_radix16(const DeviceTables* tab, const u64* s_tab, int n_entri
 // JacobianPoint::multiply / AffinePoint::multiply (ACC = MJac,
 // src/curve/jacobian.rs:599-611, src/curve/affine.rs:373-375): same loop, the
 // accumulator type is the only difference.
-template <class ACC, int IN_FORM, int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
+// DIRECT (variable time, affine results only): the same fixed-window ladder with the table entry
+// read by index instead of scanned -- the fast path of the multiply_vartime entry point.  An affine
+// result does not depend on the ladder, and for a scalar below 2^255 (every canonical one) the NAF
+// ladder and this one give the same point; a wave with a scalar that has bit 255 set is left to
+// k_multiply_vartime<..., ONLY_WIDE>, which runs the reference's NAF ladder for it.
+template <class ACC, int IN_FORM, int OUT_FORM, bool DIRECT = false>
+__global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                        const u8* __restrict__ scalars, u64* __restrict__ out,
                                                        u8* __restrict__ inf, size_t n, u64* __restrict__ scratch) {
     __shared__ i8 s_digits[64 * BLOCK];
@@ -635,10 +656,11 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __
         // canonical scalars (< 2^255) only ever select entries 1..8; a wave builds
         // all 16 entries of LookupTable<16> only if one of its lanes needs them
         const bool wide = (k[3] >> 60) > 7;
+        if (DIRECT && __any((int)(k[3] >> 63))) continue;  // this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
         const Proj p = load_input_point<IN_FORM>(pts, ii);
         const u32 ident = build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
-        const ACC acc = ladder_radix16<ACC, false>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
+        const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
 }
@@ -648,8 +670,10 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_ct(const DeviceTables* __
 // src/curve/jacobian.rs:619-649, src/curve/affine.rs:384-386), with their
 // quirk Q1: the "skip unset digits" loop never moves i off 255, so there are
 // always 256 doublings and the correction is MINUS_SHIFT_POINT_ARRAY[256].
-template <class ACC, int IN_FORM, int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTables* __restrict__ tab,
+// ONLY_WIDE: run only the waves that hold a scalar with bit 255 set (whose NAF recoding drops the
+// final carry, src/scalar.rs:585-643); the others were done by k_multiply_ct<..., DIRECT>.
+template <class ACC, int IN_FORM, int OUT_FORM, bool ONLY_WIDE = false>
+__global__ void __launch_bounds__(BLOCK, CH_VT_WAVES) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n,
                                                             u64* __restrict__ scratch, int uniform_scalar) {
@@ -667,26 +691,12 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_vartime(const DeviceTable
         const size_t ii = active ? i : n - 1;
         u64 k[4];
         load_scalar(scalars, uniform_scalar ? 0 : ii, k);  // uniform: is_torsion_free / clear_cofactor (one fixed scalar)
-        // AFFINE results do not depend on the ladder: for scalars below 2^255 (every canonical one) the NAF
-        // ladder and the radix-16 ladder give the same point, and a wave whose lanes all stay in step on
-        // the fixed windows is faster than one whose lanes diverge on their NAF digits.  So such a wave
-        // runs the fixed-window ladder with indexed lookups.  A scalar with bit 255 set sends its wave
-        // down the reference's NAF ladder (whose recoding drops the final carry there, src/scalar.rs:585-643);
-        // the (X, Y, Z) outputs and the one-scalar launches always take it.
-        const bool fixed_windows = OUT_FORM == 0 && !uniform_scalar && !__any((int)(k[3] >> 63));
+        if (ONLY_WIDE && !__syncthreads_or((int)(k[3] >> 63))) continue;  // no such scalar in this workgroup
         __syncthreads();
-        if (fixed_windows)
-            recode_radix16(k, s_naf, t);
-        else
-            recode_wnaf(k, 5, s_naf, t);
+        recode_wnaf(k, 5, s_naf, t);
         __syncthreads();
+        if (ONLY_WIDE && !__any((int)(k[3] >> 63))) continue;
         const Proj p = load_input_point<IN_FORM>(pts, ii);
-        if (fixed_windows) {
-            const u32 ident8 = build_table<false>(p, 8, s_tab, s_z, s_prefix, t);  // top digit <= 7 below 2^255
-            const ACC r16 = ladder_radix16<ACC, true>(tab, s_tab, 8, ident8, s_naf, t, mshift);
-            if (active) emit_point<OUT_FORM>(out, inf, i, r16);
-            continue;
-        }
         const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
         ACC acc = Ladder<ACC>::from_affine(shift);
         // Every lane runs ITS OWN reference sequence (256 doublings, an addition after
