@@ -105,18 +105,19 @@ def main():
     torch.cuda.synchronize()
     local_of = {g0: j for j, (c, g0) in enumerate(plan[rank])}
     def step(timed_kernel=False):
-        if timed_kernel:  # one un-overlapped pass with HIP events around each launch on its stream
+        if timed_kernel:  # one un-overlapped pass, HIP events on the launch stream around each call's kernel launches
             total = 0.0
             launches = 0
             xy = torch.empty((s, 12), dtype=torch.int64, device=device)
             inf = torch.empty((s,), dtype=torch.uint8, device=device)
+            upl = eng.multiply_units_per_launch(s, False, AFFINE)  # the library bounds each k_multiply_ct launch
             for j in range(chunks):
                 eng._use_torch_stream()
                 eng.timer_start()
                 eng.multiply_batch(pts[j * s:(j + 1) * s], ks[j * s:(j + 1) * s], AFFINE, AFFINE, out=xy, inf=inf)
                 total += eng.timer_stop_ms()
-                launches += 1
-            return total / launches
+                launches += -(-s // upl)
+            return total / launches, chunks * s / launches, launches
         return sharded_apply(lambda g0, cnt, oxy, oinf: eng.multiply_batch(pts[local_of[g0] * s:(local_of[g0] + 1) * s],
                                                                            ks[local_of[g0] * s:(local_of[g0] + 1) * s],
                                                                            AFFINE, AFFINE, out=oxy, inf=oinf),
@@ -145,10 +146,16 @@ def main():
     n_inf = int(inf.sum().item())
 
     # ---- roofline of the dominant kernel (k_multiply_ct), measured live ---------
-    ms_launch = step(timed_kernel=True)          # HIP events on the launch stream
-    units_per_launch = s
+    ms_launch, units_per_launch, n_launches = step(timed_kernel=True)   # averages over the pass's kernel launches
     mad_peak = eng.calibrate_mad_peak()          # T v_mad_u64_u32 / s, measured on this device
     achieved = units_per_launch * MAD32_PER_CT_MULT / (ms_launch * 1e-3) / 1e12
+    traffic = None                               # HBM bytes per launch from the committed PMC passes (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tr = json.load(f)["k_multiply_ct"]
+        traffic = (tr["fetch_bytes_per_unit"] + tr["write_bytes_per_unit"]) * units_per_launch
+    except (OSError, KeyError, ValueError):
+        pass
 
     # ---- secondary metric: elementwise Fp6 multiplication (config 1, 2^20 pairs) --
     nf = 1 << 20
@@ -187,13 +194,16 @@ def main():
             "checksum": "%016x" % checksum,
             "identities": n_inf,
             "roofline": {"bound": "valu", "kernel": "k_multiply_ct", "achieved": achieved, "peak": mad_peak,
-                         "unit": "Tmad32/s", "frac": achieved / mad_peak, "traffic": None,
-                         "ms_per_launch": ms_launch, "units_per_launch": units_per_launch,
+                         "unit": "Tmad32/s", "frac": achieved / mad_peak, "traffic": traffic,
+                         "ms_per_launch": ms_launch, "units_per_launch": units_per_launch, "launches_per_pass": n_launches,
                          "mad32_per_unit": MAD32_PER_CT_MULT,
                          "frac_if_credited_as_ProjectivePoint_multiply": achieved * MAD32_PER_CT_MULT_PROJECTIVE / MAD32_PER_CT_MULT / mad_peak,
                          "note": "achieved = reference-algorithm mad32 count of AffinePoint::multiply (72588 Fp mul x 4) x units / "
                                  "HIP-event launch time; peak = v_mad_u64_u32 issue rate measured live on this device; the kernel "
-                                 "is VALU-issue bound (profiles/, DESIGN.md 5): carries and reductions issue at the same rate as the mads"},
+                                 "is VALU-issue bound (profiles/, DESIGN.md 5): carries and reductions issue at the same rate as the mads; "
+                                 "ms_per_launch / units_per_launch are per k_multiply_ct kernel launch (the library bounds each launch); "
+                                 "traffic = (FETCH_SIZE + WRITE_SIZE) per unit from the rocprofv3 PMC passes in profiles/ x units_per_launch: "
+                                 "the lane's window table is re-read in each of the 64 windows (algorithmic bytes: 225 per unit)"},
             "roofline_fp6_mul": {"bound": "hbm", "kernel": "k_fp6_elementwise<mul>", "achieved": fp6_gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": fp6_gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": fp6_ms,
                                  "units_per_launch": nf, "bytes_per_unit": FP6_MUL_BYTES},

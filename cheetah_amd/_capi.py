@@ -68,6 +68,7 @@ SIGNATURES = {
     "cheetah_synth_scalars_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _sz]),
     "cheetah_debug_op_dev": (C.c_int32, [_vp, _i, _vp, _vp, _vp, _sz]),
     "cheetah_calibrate_mad_peak": (C.c_int32, [_vp, C.POINTER(C.c_double)]),
+    "cheetah_multiply_units_per_launch": (C.c_int32, [_vp, _sz, _i, _i, C.POINTER(C.c_size_t)]),
     "cheetah_timer_start": (C.c_int32, [_vp]),
     "cheetah_timer_stop_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
 }

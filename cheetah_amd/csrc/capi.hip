@@ -902,6 +902,14 @@ extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t
     return CHEETAH_OK;
 }
 
+extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n, int vartime, int out_form, size_t* units) {
+    CHECK_CTX(ctx);
+    if (!units) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    const int waves = (vartime && out_form != CHEETAH_AFFINE) ? CH_VT_WAVES : CH_CT_WAVES;
+    const size_t per_launch = (size_t)lane_grid(ctx, n ? n : 1, waves) * BLOCK * ROUNDS_PER_LAUNCH;
+    *units = n < per_launch ? n : per_launch;
+    return CHEETAH_OK;
+}
 extern "C" int32_t cheetah_calibrate_mad_peak(cheetah_ctx* ctx, double* tera_mads_per_s) {
     CHECK_CTX(ctx);
     if (!tera_mads_per_s) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");

@@ -167,6 +167,29 @@ struct Acc3 {
               [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
             : [al] "v"(lo32(a)), [ah] "v"(hi32(a)), [bl] "v"(lo32(b)), [bh] "v"(hi32(b)));
     }
+    // acc = a * b + c * d: init and the first mac in one block.  The carry counters are SET by the
+    // first carries that can occur, so none needs zeroing first.
+    CH_DEV void init2(u64 a, u64 b, u64 c, u64 d) {
+        u64 s0, s1, s2;
+        asm("v_mad_u64_u32 %[c1], %[s1], %[al], %[bh], 0\n\t"
+            "v_mad_u64_u32 %[c0], %[s0], %[al], %[bl], 0\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[ah], %[bl], %[c1]\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[ah], %[bh], 0\n\t"
+            "v_mad_u64_u32 %[c0], %[s0], %[cl], %[dl], %[c0]\n\t"
+            "v_addc_co_u32 %[t1], %[s1], 0, 0, %[s1]\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[cl], %[dh], %[c1]\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[ch], %[dh], %[c2]\n\t"
+            "v_addc_co_u32 %[t0], %[s0], 0, 0, %[s0]\n\t"
+            "v_addc_co_u32 %[t1], %[s1], 0, %[t1], %[s1]\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[ch], %[dl], %[c1]\n\t"
+            "v_addc_co_u32 %[t2], %[s2], 0, 0, %[s2]\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %[t1], %[s1], 0, %[t1], %[s1]"
+            : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+              [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [al] "v"(lo32(a)), [ah] "v"(hi32(a)), [bl] "v"(lo32(b)), [bh] "v"(hi32(b)), [cl] "v"(lo32(c)),
+              [ch] "v"(hi32(c)), [dl] "v"(lo32(d)), [dh] "v"(hi32(d)));
+    }
     // acc += a * b
     CH_DEV void mac(u64 a, u64 b) {
         u64 s0, s1, s2;

@@ -122,9 +122,9 @@ CH_FP6_FN fp6v fp6_mul_fn(fp6v av, fp6v bv) {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         Acc3 acc;
-        acc.init(a.c[0], b.c[k]);
+        acc.init2(a.c[0], b.c[k], a.c[1], k >= 1 ? b.c[k - 1] : b7[5]);
 #pragma unroll
-        for (int i = 1; i < 6; i++) {
+        for (int i = 2; i < 6; i++) {
             if (i <= k)
                 acc.mac(a.c[i], b.c[k - i]);
             else
@@ -152,7 +152,8 @@ CH_FP6_FN fp6v fp6_square_fn(fp6v av) {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         Acc3 acc;
-        bool started = false;
+        int seen = 0;  // every coefficient has at least three terms
+        u64 x0 = 0, y0 = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
 #pragma unroll
@@ -161,12 +162,15 @@ CH_FP6_FN fp6v fp6_square_fn(fp6v av) {
                 if (low || high) {
                     const u64 x = (i == j) ? a.c[i] : d[i];
                     const u64 y = high ? s[j] : a.c[j];
-                    if (!started) {
-                        acc.init(x, y);
-                        started = true;
+                    if (seen == 0) {
+                        x0 = x;
+                        y0 = y;
+                    } else if (seen == 1) {
+                        acc.init2(x0, y0, x, y);
                     } else {
                         acc.mac(x, y);
                     }
+                    seen++;
                 }
             }
         }
@@ -211,9 +215,9 @@ CH_DEV Fp6 fp6_frobenius_triple(const Fp6& a) {
 // Only coefficient 0 of a * b (the Fp-valued norm step of the inversion).
 CH_DEV u64 fp6_mul_c0(const Fp6& a, const Fp6& b) {
     Acc3 acc;
-    acc.init(a.c[0], b.c[0]);
+    acc.init2(a.c[0], b.c[0], a.c[1], fp_mul_small(b.c[5], 7u));
 #pragma unroll
-    for (int i = 1; i < 6; i++) acc.mac(a.c[i], fp_mul_small(b.c[6 - i], 7u));
+    for (int i = 2; i < 6; i++) acc.mac(a.c[i], fp_mul_small(b.c[6 - i], 7u));
     return acc.reduce();
 }
 
@@ -256,16 +260,13 @@ CH_DEV Fp3 fp3_zero() {
 __device__ __noinline__ void fp3_mul_fn(const u64 x0, const u64 x1, const u64 x2, const u64 y0, const u64 y1, const u64 y2, u64* out) {
     const u64 y1s = fp_mul_small(y1, 7u), y2s = fp_mul_small(y2, 7u);
     Acc3 acc;
-    acc.init(x0, y0);
-    acc.mac(x1, y2s);
+    acc.init2(x0, y0, x1, y2s);
     acc.mac(x2, y1s);
     out[0] = acc.reduce();
-    acc.init(x0, y1);
-    acc.mac(x1, y0);
+    acc.init2(x0, y1, x1, y0);
     acc.mac(x2, y2s);
     out[1] = acc.reduce();
-    acc.init(x0, y2);
-    acc.mac(x1, y1);
+    acc.init2(x0, y2, x1, y1);
     acc.mac(x2, y0);
     out[2] = acc.reduce();
 }

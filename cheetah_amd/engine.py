@@ -402,6 +402,12 @@ class Engine:
         self._check(self._lib.cheetah_calibrate_mad_peak(self._h, C.byref(v)))
         return v.value
 
+    def multiply_units_per_launch(self, n, vartime=False, out_form=AFFINE):
+        """Scalar multiplications per kernel launch for a batch of n (the library bounds each launch)."""
+        v = C.c_size_t()
+        self._check(self._lib.cheetah_multiply_units_per_launch(self._h, n, 1 if vartime else 0, out_form, C.byref(v)))
+        return v.value
+
     def timer_start(self):
         self._check(self._lib.cheetah_timer_start(self._h))
 

@@ -232,6 +232,11 @@ typedef enum {
 int32_t cheetah_debug_op_dev(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 /* Measured v_mad_u64_u32 issue rate of this device in 1e12 lane-ops/s (roofline denominator). */
 int32_t cheetah_calibrate_mad_peak(cheetah_ctx *ctx, double *tera_mads_per_s);
+/* How many scalar multiplications one kernel launch of cheetah_multiply_batch_dev (vartime = 0) or
+ * cheetah_multiply_vartime_batch_dev (vartime = 1) covers for a batch of n: the library bounds a launch to
+ * a few rounds of the resident grid, so a large batch is a sequence of launches.  For per-launch rooflines
+ * (bench.py); no counterpart in the reference. */
+int32_t cheetah_multiply_units_per_launch(cheetah_ctx *ctx, size_t n, int vartime, int out_form, size_t *units);
 /* Time of the last `_dev` kernel sequence bracketed by HIP events on the ctx stream. */
 int32_t cheetah_timer_start(cheetah_ctx *ctx);
 int32_t cheetah_timer_stop_ms(cheetah_ctx *ctx, float *ms);
