@@ -117,6 +117,7 @@ extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
     CREATE_TRY(hipMemcpyAsync(seeds, GENERATOR_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyAsync(seeds + 12, SHIFT_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(BUILD_TABLES_THREADS), 0, ctx->stream, ctx->tables, seeds, seeds + 12);
+    hipLaunchKernelGGL(k_build_wide_table, dim3(WIDE_WINDOWS), dim3(64), 0, ctx->stream, ctx->tables, seeds);
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
     CREATE_TRY(hipFree(seeds));
@@ -271,6 +272,18 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
     if (n == 0) return CHEETAH_OK;
     if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    if (out_form == CHEETAH_AFFINE) {  // affine results: the widened comb (one 1 024-thread workgroup per CU)
+        size_t want = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
+        int grid_w = (int)(want < (size_t)ctx->num_cus ? want : (size_t)ctx->num_cus);
+        const size_t per_launch_w = (size_t)grid_w * WIDE_BLOCK * ROUNDS_PER_LAUNCH * 4;
+        for (size_t off = 0; off < n; off += per_launch_w) {
+            const size_t cnt = n - off < per_launch_w ? n - off : per_launch_w;
+            hipLaunchKernelGGL(k_mul_by_generator_wide, dim3(grid_w), dim3(WIDE_BLOCK), 0, ctx->stream, ctx->tables,
+                               scalars32 + off * 32, out + off * 12, inf + off, cnt);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return CHEETAH_OK;
+    }
     int grid = lane_grid(ctx, n, CH_GEN_WAVES);
     const size_t out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
     const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH * 4;  // bounded launches, as in multiply_dev

@@ -41,7 +41,11 @@ struct DeviceTables {
     // computed once with the same formulas.
     u64 shift16_proj[18];            // double_unchecked^4(ProjectivePoint::from(S)): x | y | z
     u64 shift16_mjac[24];            // double_unchecked^4(ModifiedJacobianPoint::from(S)): x | y | z | z4
+    // Fixed-base table of k_mul_by_generator_wide (affine results only; no counterpart in the reference):
+    // wide[j][e] = (e + 1) 64^j G, window-major, entry-major, x|y.
+    u64 wide[43 * 32 * 12];
 };
+constexpr int WIDE_BITS = 6, WIDE_WINDOWS = 43, WIDE_ENTRIES = 32, WIDE_BLOCK = 1024;
 
 // ---- AoS <-> register helpers --------------------------------------------
 CH_DEV Fp6 load_fp6(const u64* p) {
@@ -425,6 +429,85 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const 
         if (active) {
             emit_point<OUT_FORM>(out, inf, i, acc);
             if (!in_range && inf) inf[i] = 0xFF;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fixed base, constant time, AFFINE results: the same point as BasePointTable::multiply
+// (src/lookup.rs:189-206) by a schedule the hardware likes better.  An affine result does not
+// depend on how k G was reached, so the comb is widened until no doubling is left: signed
+// radix-64 digits d_j in [-32, 32) (k = sum d_j 64^j, 43 windows) and one 32-entry table
+// (e + 1) 64^j G per window -- 43 mixed additions instead of 65 additions + 4 doublings.  The
+// 129 KiB table is staged once per 1 024-thread workgroup in LDS (gfx950: 160 KiB per CU); a
+// lookup reads all 32 entries of the window at wave-uniform addresses and keeps one by selects
+// (constant time, as the reference's scan, src/lookup.rs:81-102).  The accumulator starts from
+// the shift point S and S is subtracted at the end, so the incomplete addition never meets the
+// identity (the reference's own device, src/lookup.rs:196, :205).  Digits are recoded on the fly.
+__global__ void __launch_bounds__(64) k_build_wide_table(DeviceTables* tab, const u64* gen_xy) {
+    const int j = blockIdx.x, e = threadIdx.x;  // entry (e + 1) 64^j G
+    if (e >= WIDE_ENTRIES) return;
+    Proj base = proj_from_affine(load_affine(gen_xy));
+    for (int i = 0; i < WIDE_BITS * j; i++) base = proj_double(base);
+    Proj acc = proj_identity();
+    for (int b = 5; b >= 0; b--) {  // (e + 1) <= 32 by left-to-right double-and-add, complete formulas
+        acc = proj_double(acc);
+        Proj sum = proj_add(acc, base);
+        if (((e + 1) >> b) & 1) acc = sum;
+    }
+    store_affine(tab->wide, nullptr, (size_t)(j * WIDE_ENTRIES + e), affine_from_proj(acc));
+}
+
+CH_DEV Affine lds_lookup32(const u64* sub /* 32 x 12 limbs in LDS */, int d) {
+    const int neg = d < 0;
+    const int dabs = neg ? -d : d;
+    Affine t = affine_identity();
+#pragma unroll 4
+    for (int j = 1; j <= WIDE_ENTRIES; j++) {
+        const bool hit = (dabs == j);
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            u64 vx = sub[(j - 1) * 12 + l], vy = sub[(j - 1) * 12 + 6 + l];
+            t.x.c[l] = hit ? vx : t.x.c[l];
+            t.y.c[l] = hit ? vy : t.y.c[l];
+        }
+        t.inf = hit ? false : t.inf;
+    }
+    return affine_cond_neg(t, neg);
+}
+
+__global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const DeviceTables* __restrict__ tab,
+                                                                        const u8* __restrict__ scalars, u64* __restrict__ out,
+                                                                        u8* __restrict__ inf, size_t n) {
+    __shared__ u64 s_wide[WIDE_WINDOWS * WIDE_ENTRIES * 12];
+    const int t = threadIdx.x;
+    for (int w = t; w < WIDE_WINDOWS * WIDE_ENTRIES * 12; w += WIDE_BLOCK) s_wide[w] = tab->wide[w];
+    const Affine shift = load_affine(tab->shift);
+    __syncthreads();
+    const size_t nround = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i = round * WIDE_BLOCK + t;
+        const bool active = i < n;
+        u64 k[4];
+        load_scalar(scalars, active ? i : n - 1, k);
+        const bool in_range = (k[3] >> 60) <= 7;  // the range BasePointTable::multiply covers (Q3); flagged as there
+        MJac acc = mjac_from_affine(shift);
+        int carry = 0;
+#pragma unroll 1
+        for (int j = 0; j < WIDE_WINDOWS; j++) {
+            int d = (int)(k[0] & 63) + carry;  // the top window holds bits 252..255 only: never re-centred
+            carry = d >= 32 ? 1 : 0;           // d in [0, 64]
+            d -= carry << 6;
+            k[0] = (k[0] >> 6) | (k[1] << 58);
+            k[1] = (k[1] >> 6) | (k[2] << 58);
+            k[2] = (k[2] >> 6) | (k[3] << 58);
+            k[3] >>= 6;
+            acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, lds_lookup32(s_wide + j * (WIDE_ENTRIES * 12), d));
+        }
+        acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, affine_cond_neg(shift, true));
+        if (active) {
+            emit_point<0>(out, inf, i, acc);
+            if (!in_range) inf[i] = 0xFF;
         }
     }
 }

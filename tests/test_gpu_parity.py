@@ -379,6 +379,27 @@ def test_mul_by_generator_seeded_vs_oracle(eng, ora, n):
     assert (host(eng.synth_scalars(2, n)) == sc).all()
 
 
+def test_mul_by_generator_wide_comb_edges(eng, ora):
+    """The affine-result fixed-base kernel (signed radix-64 comb, 43 windows, no doublings) against the
+    oracle's BASEPOINT_TABLE.multiply on scalars that stress its recoding: digits at the re-centring
+    boundary (31 / 32 / 33 / 63 in every window), carry chains through all windows, 0, 1, q - 1, q
+    (identity) and the largest scalar the reference's comb covers (2^255 - 1)."""
+    from cheetah_amd import AFFINE
+    ks = [0, 1, 2, 31, 32, 33, 63, 64, 65, Q - 1, Q, Q + 1, (1 << 255) - 1, (1 << 255) - 64, (1 << 252) - 1, 1 << 252]
+    for j in range(43):
+        for d in (31, 32, 33, 63):
+            k = d << (6 * j)
+            if k < (1 << 255):
+                ks.append(k)
+    ks += [int("ff" * 31, 16), int("df" * 31 + "20", 16), sum(32 << (6 * j) for j in range(42)), sum(63 << (6 * j) for j in range(42)),
+           sum(31 << (6 * j) for j in range(42))]
+    sc = np.array([np.frombuffer(int(k).to_bytes(32, "little"), np.uint8) for k in ks], np.uint8)
+    xy, inf = eng.mul_by_generator_batch(dev(sc), AFFINE)
+    wxy, winf = ora.mul_by_generator_batch(sc, 0)
+    assert (host(xy) == wxy).all() and (host(inf) == winf).all()
+    assert host(inf)[0] == 1 and host(inf)[ks.index(Q)] == 1  # 0 G = q G = identity
+
+
 def test_basepoint_lookup_jacobian(eng, ora):
     """`&BASEPOINT_LOOKUP * &Scalar` (src/constants.rs:102-135): the reference's Jacobian
     (X, Y, Z), edge scalars included (digit 31 wraps to -128 for a top byte of 0x7f + carry,
