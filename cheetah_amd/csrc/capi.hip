@@ -314,7 +314,8 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
     // multiply_vartime with AFFINE results: the fixed-window ladder with indexed lookups (k_multiply_ct<..., DIRECT>)
     // for every wave whose scalars are all below 2^255, then the reference's NAF ladder for the remaining waves.
     const bool direct = VARTIME && out_form == CHEETAH_AFFINE;
-    const int grid_vt = lane_grid(ctx, n, CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
+    // the ONLY_WIDE instance of the NAF kernel (normally nothing to do) is compiled for 2 waves: no scratch
+    const int grid_vt = lane_grid(ctx, n, direct ? 2 : CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
     const int grid = (VARTIME && !direct) ? grid_vt : grid_ct;
     if (int32_t rc = ensure_scratch(ctx, (size_t)(grid_vt > grid_ct ? grid_vt : grid_ct) * LaneScratch::WORDS_PER_BLOCK)) return rc;
     // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (~25 ms of
@@ -529,7 +530,7 @@ static int32_t multiply_many_dev(cheetah_ctx* ctx, const u64* pts, int in_form, 
     if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     const int ns = m + (with_basepoint ? 1 : 0);
-    int grid = lane_grid(ctx, n_groups, 2);
+    int grid = lane_grid(ctx, n_groups, CH_MANY_WAVES);
     const size_t wpb = ManyScratch::words(m, ns);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * wpb)) return rc;
     const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;

@@ -12,15 +12,18 @@ constexpr int BLOCK = 256;
 // Waves per SIMD (= 256-thread workgroups per CU) the kernels are compiled and launched for.
 // Measured at 2^20 / 2^24 (tools/ladder_bench.py, tools/bn_bench.py; waves 2 / 3 / 4): constant-time ladder
 // 25.6 / 27.8 / 28.4 M/s (at 128 VGPRs the window loop keeps two spill accesses, the rest are in the table
-// build), fixed base 91 / 97 / 100 M/s, batch_normalize 7.2 / 7.4 / 7.2 G/s; the NAF kernel loses at 3.
+// build), fixed base 91 / 97 / 100 M/s, batch_normalize 7.2 / 7.4 / 7.2 G/s.
 #ifndef CH_CT_WAVES
 #define CH_CT_WAVES 4
 #endif
 #ifndef CH_VT_WAVES
-#define CH_VT_WAVES 2
+#define CH_VT_WAVES 4   // NAF ladder (packed digits: 16 KiB of LDS): 15.8 / 17.3 / 17.8 M/s at 2 / 3 / 4 waves
 #endif
 #ifndef CH_GEN_WAVES
 #define CH_GEN_WAVES 4
+#endif
+#ifndef CH_MANY_WAVES
+#define CH_MANY_WAVES 2
 #endif
 #ifndef CH_BN_WAVES
 #define CH_BN_WAVES 3
@@ -369,6 +372,45 @@ CH_DEV void recode_wnaf(const u64 k[4], int w, i8* naf /* [256][BLOCK] */, int t
         }
         pos += w;
     }
+}
+
+// The same width-5 NAF packed for LDS: a non-zero digit is followed by at least four zeros, so any four
+// consecutive positions hold at most one.  One byte per block of four positions:
+//   bit 7 = the block has a digit, bits 5:4 = its position in the block, bit 3 = sign, bits 2:0 = (|d| - 1) / 2.
+// 64 bytes per lane instead of 256 (16 KiB per workgroup: the NAF kernel's occupancy is then set by VGPRs).
+CH_DEV void recode_wnaf5_packed(const u64 k[4], u8* naf4 /* [64][BLOCK] */, int t) {
+    for (int i = 0; i < 64; i++) naf4[i * BLOCK + t] = 0;
+    const u32 width = 32, mask = 31;
+    u32 carry = 0;
+    int pos = 0;
+    while (pos < 256) {
+        const int idx = pos >> 6, bit = pos & 63;
+        u64 lo = idx == 0 ? k[0] : idx == 1 ? k[1] : idx == 2 ? k[2] : k[3];
+        u64 hi = idx == 0 ? k[1] : idx == 1 ? k[2] : idx == 2 ? k[3] : 0ull;
+        u64 buf = (bit < 64 - 5) ? (lo >> bit) : ((lo >> bit) | (hi << (64 - bit)));
+        const u32 window = carry + ((u32)buf & mask);
+        if ((window & 1) == 0) {
+            pos += 1;
+            continue;
+        }
+        int d;
+        if (window < width / 2) {
+            carry = 0;
+            d = (int)window;
+        } else {
+            carry = 1;
+            d = (int)window - (int)width;
+        }
+        const u32 mag = (u32)(d < 0 ? -d : d);
+        naf4[(pos >> 2) * BLOCK + t] = (u8)(0x80u | ((u32)(pos & 3) << 4) | (d < 0 ? 8u : 0u) | ((mag - 1) >> 1));
+        pos += 5;
+    }
+}
+CH_DEV int naf4_digit(const u8* naf4, int pos, int t) {
+    const u32 b = naf4[(pos >> 2) * BLOCK + t];
+    if (!(b & 0x80u) || ((b >> 4) & 3u) != (u32)(pos & 3)) return 0;
+    const int mag = (int)((b & 7u) * 2 + 1);
+    return (b & 8u) ? -mag : mag;
 }
 
 CH_DEV void load_scalar(const u8* scalars, size_t i, u64 k[4]) {
@@ -756,11 +798,11 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
 // ONLY_WIDE: run only the waves that hold a scalar with bit 255 set (whose NAF recoding drops the
 // final carry, src/scalar.rs:585-643); the others were done by k_multiply_ct<..., DIRECT>.
 template <class ACC, int IN_FORM, int OUT_FORM, bool ONLY_WIDE = false>
-__global__ void __launch_bounds__(BLOCK, CH_VT_WAVES) k_multiply_vartime(const DeviceTables* __restrict__ tab,
+__global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n,
                                                             u64* __restrict__ scratch, int uniform_scalar) {
-    __shared__ i8 s_naf[256 * BLOCK];
+    __shared__ u8 s_naf[64 * BLOCK];
     const int t = threadIdx.x;
     u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
     u64* s_z = s_tab + (size_t)16 * 12 * BLOCK;
@@ -776,7 +818,7 @@ __global__ void __launch_bounds__(BLOCK, CH_VT_WAVES) k_multiply_vartime(const D
         load_scalar(scalars, uniform_scalar ? 0 : ii, k);  // uniform: is_torsion_free / clear_cofactor (one fixed scalar)
         if (ONLY_WIDE && !__syncthreads_or((int)(k[3] >> 63))) continue;  // no such scalar in this workgroup
         __syncthreads();
-        recode_wnaf(k, 5, s_naf, t);
+        recode_wnaf5_packed(k, s_naf, t);
         __syncthreads();
         if (ONLY_WIDE && !__any((int)(k[3] >> 63))) continue;
         const Proj p = load_input_point<IN_FORM>(pts, ii);
@@ -810,7 +852,7 @@ __global__ void __launch_bounds__(BLOCK, CH_VT_WAVES) k_multiply_vartime(const D
             }
             if (can) {
                 acc = Ladder<ACC>::dbl(acc);
-                pd = s_naf[pos * BLOCK + t];
+                pd = naf4_digit(s_naf, pos, t);
                 pos--;
             }
         }
@@ -837,7 +879,7 @@ struct ManyScratch {
 };
 
 template <class ACC, int IN_FORM, int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
+__global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                             const u8* __restrict__ scalars, u64* __restrict__ out,
                                                             u8* __restrict__ inf, size_t n_groups, int m,
                                                             u64* __restrict__ scratch, size_t words_per_block) {
@@ -883,7 +925,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_ct(const DeviceTable
 }
 
 template <class ACC, int IN_FORM, int OUT_FORM>
-__global__ void __launch_bounds__(BLOCK, 2) k_multiply_many_vartime(const DeviceTables* __restrict__ tab,
+__global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(const DeviceTables* __restrict__ tab,
                                                                  const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                                  u64* __restrict__ out, u8* __restrict__ inf, size_t n_groups,
                                                                  int m, int with_basepoint, u64* __restrict__ scratch,
