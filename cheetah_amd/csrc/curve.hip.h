@@ -59,37 +59,21 @@ CH_DEV Affine affine_cond_neg(const Affine& a, bool negate) {
     return r;
 }
 
-// src/curve/projective.rs:400-443
+// src/curve/projective.rs:400-443.  Same field elements as the reference's sequence; its runs of doublings are
+// taken as one small-constant product (8c = 2 (4c), 8 t3^2 instead of 2 (2 t3)^2, 8 b^3 instead of 2 (2b)^2 b).
 CH_DEV Proj proj_double_unchecked(const Proj& s) {
-    Fp6 x2 = fp6_square(s.x);
-    Fp6 z2 = fp6_square(s.z);
-    Fp6 a = fp6_double(x2);
-    a = fp6_add(a, x2);
-    a = fp6_add(a, z2);
+    Fp6 a = fp6_triple(fp6_square(s.x));
+    a = fp6_add(a, fp6_square(s.z));             // 3 x^2 + z^2
     Fp6 b = fp6_mul(s.y, s.z);
     Fp6 t3 = fp6_mul(s.y, b);
     Fp6 c = fp6_mul(t3, s.x);
-    Fp6 d = fp6_double(c);
-    Fp6 c4 = fp6_double(d);
-    d = fp6_double(c4);
-    Fp6 t = fp6_square(a);
-    d = fp6_sub(t, d);
-    Fp6 x3 = fp6_mul(b, d);
-    x3 = fp6_double(x3);
-    Fp6 y3 = fp6_sub(c4, d);
-    y3 = fp6_mul(a, y3);
-    t3 = fp6_double(t3);
-    t3 = fp6_square(t3);
-    t3 = fp6_double(t3);
-    y3 = fp6_sub(y3, t3);
-    Fp6 z3 = fp6_double(b);
-    z3 = fp6_square(z3);
-    z3 = fp6_mul(z3, b);
-    z3 = fp6_double(z3);
+    t3 = fp6_mul_small(fp6_square(t3), 8u);      // 8 (y b)^2
+    Fp6 c4 = fp6_mul_small(c, 4u);
+    Fp6 d = fp6_sub(fp6_square(a), fp6_double(c4));  // a^2 - 8c
     Proj r;
-    r.x = x3;
-    r.y = y3;
-    r.z = z3;
+    r.x = fp6_double(fp6_mul(b, d));
+    r.y = fp6_sub(fp6_mul(a, fp6_sub(c4, d)), t3);
+    r.z = fp6_mul_small(fp6_mul(fp6_square(b), b), 8u);
     return r;
 }
 
