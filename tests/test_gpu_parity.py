@@ -41,6 +41,14 @@ def host(t):
     return t.cpu().numpy()
 
 
+def take(t, idx):
+    """Rows idx of a device tensor (uint64 tensors cannot be indexed on the device: go through int64)."""
+    import torch
+    if t.dtype == torch.uint64:
+        return t.view(torch.int64)[idx].view(torch.uint64)
+    return t[idx]
+
+
 EDGE_FP = [0, 1, 2, 7, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1, 2**32 + 1, 2**63, 2**63 - 1, P - 2**32, 0xFFFFFFFF00000000]
 
 
@@ -745,6 +753,41 @@ def test_full_size_configs_2_3_properties(eng, ora):
     qb = torch.from_numpy(np.frombuffer(Q.to_bytes(32, "little"), np.uint8).copy()).cuda().repeat(n, 1).contiguous()
     _, i_q = eng.multiply_vartime_batch(r_vt, qb, AFFINE, AFFINE)
     assert int(i_q.sum()) == n
+    # config 3 as BASELINE.json words it: ProjectivePoint::multiply_vartime (every lane its own NAF sequence);
+    # its (X:Y:Z), normalised, must be the same 2^22 affine points
+    from cheetah_amd import PROJECTIVE
+    pr, _ = eng.multiply_vartime_batch(pts, K, AFFINE, PROJECTIVE)
+    nxy, ninf = eng.batch_normalize(pr, PROJECTIVE)
+    assert torch.equal(nxy.view(torch.int64), r_ct.view(torch.int64)) and torch.equal(ninf, i_ct)
+    didx = torch.from_numpy(idx).cuda()
+    wpr, _ = ora.multiply_batch(host(take(pts, didx)), 0, host(K)[idx], 1, vartime=True)
+    assert (host(take(pr, didx)) == wpr).all()
+
+
+def test_full_size_config5_properties(eng, ora):
+    """BASELINE config 5 at full size (2^26 seeded (P_i, k_i), bench.py's inputs), in four blocks of 2^24:
+    constant-time == variable-time for ALL i (scan vs indexed lookups), a strided sample against the oracle,
+    no identities, and the wrap-around sum of all canonical limbs equals the checksum bench.py prints
+    (profiles/r01_bench_2p26.json) -- a checksum of checksums over the blocks."""
+    import torch
+    from cheetah_amd import AFFINE
+    m, blocks = 1 << 24, 4
+    total = 0
+    for c in range(blocks):
+        r = eng.synth_scalars(5, m, (1 << 26) + c * m)
+        pts, pinf = eng.mul_by_generator_batch(r, AFFINE)
+        K = eng.synth_scalars(5, m, c * m)
+        ct, ict = eng.multiply_batch(pts, K, AFFINE, AFFINE)
+        vt, ivt = eng.multiply_vartime_batch(pts, K, AFFINE, AFFINE)
+        assert torch.equal(ct.view(torch.int64), vt.view(torch.int64)) and torch.equal(ict, ivt)
+        assert int(ict.sum()) == 0 and int(pinf.sum()) == 0
+        total = (total + int(ct.view(torch.int64).sum().item())) & 0xFFFFFFFFFFFFFFFF
+        idx = torch.arange(c, m, m // 16, device="cuda")
+        wxy, winf = ora.multiply_batch(host(take(pts, idx)), 0, host(take(K, idx)), 0)
+        assert (host(take(ct, idx)) == wxy).all() and not winf.any()
+        del r, pts, K, ct, vt
+    with open(os.path.join(ROOT, "profiles", "r01_bench_2p26.json")) as f:
+        assert "%016x" % total == json.load(f)["checksum"]
 
 
 def test_full_size_config4_batch_normalize(eng, ora):
