@@ -208,7 +208,10 @@ static int32_t fp6_elementwise_dev(cheetah_ctx* ctx, const u64* a, const u64* b,
     if (!a || !out || (OP == EW_MUL && !b)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned16(a) || !aligned16(out) || (b && !aligned16(b))) return fail(ctx, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
     size_t tiles = (n + BLOCK - 1) / BLOCK;
-    size_t cap = (size_t)ctx->num_cus * 8;
+    // Measured (tools/fp6_ew_bench.py): batches beyond the Infinity Cache stream fastest with one element per
+    // thread (2^24 products: 5.70 TB/s against 5.06 with a resident, grid-striding launch); batches that fit it
+    // (2^20) prefer the resident grid for the shorter kernels (square: 20 us against 23).
+    size_t cap = n >= ((size_t)1 << 21) ? tiles : (size_t)ctx->num_cus * 8;
     int grid = (int)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL((k_fp6_elementwise<OP>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a, b, out, is_some, n);
     HIP_TRY(ctx, hipGetLastError());
