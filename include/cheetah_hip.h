@@ -92,10 +92,12 @@ int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx *ctx, const uint64_t *x
 
 /* ---- fixed base, constant time --------------------------------------------
  * out[i] = scalars[i] * G.
- * out_form = CHEETAH_AFFINE    : &BASEPOINT_TABLE * &Scalar = BasePointTable::multiply
- *                                (src/lookup.rs:189-206, src/constants.rs:92-98), normalised;
- *                                out = 12 limbs per point, inf[i] set
- * out_form = CHEETAH_PROJECTIVE: the same comb; out = 18 limbs per point = the reference's own
+ * out_form = CHEETAH_AFFINE    : the affine point of &BASEPOINT_TABLE * &Scalar = BasePointTable::multiply
+ *                                (src/lookup.rs:189-206, src/constants.rs:92-98); out = 12 limbs per
+ *                                point, inf[i] set.  An affine point does not depend on the schedule
+ *                                that reached it: this form runs a widened comb (signed radix-64,
+ *                                43 additions, no doublings, 129 KiB table in LDS)
+ * out_form = CHEETAH_PROJECTIVE: the reference's comb step for step; out = 18 limbs per point = the reference's own
  *                                (X:Y:Z) representative, canonical limbs; inf[i] = (Z == 0); inf may be NULL
  * out_form = CHEETAH_JACOBIAN  : &BASEPOINT_LOOKUP * &Scalar (src/constants.rs:102-135): radix-256
  *                                digits, LookupTable<128>, modified-Jacobian accumulator; out = 18
