@@ -503,6 +503,30 @@ def test_multiply_vs_oracle_all_forms(eng, ora, n):
     assert (xy == host(a1)).all() and (inf == host(i1)).all()
 
 
+def test_multiply_vartime_mixed_wide_scalars(eng, ora):
+    """multiply_vartime with AFFINE results splits a batch between two kernels: waves whose scalars are all
+    below 2^255 take the fixed-window ladder, a wave holding any scalar with bit 255 set takes the reference's
+    NAF ladder (whose recoding drops the last carry there).  Random 256-bit scalars, about one in eight with
+    bit 255 set, so that both kinds of wave occur and mix inside workgroups; against the oracle."""
+    from cheetah_amd import AFFINE, PROJECTIVE
+    n = 700
+    rng = np.random.default_rng(2024)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x7F
+    wide = rng.random(n) < 0.125
+    wide[64:256] = False          # waves 1-3 of workgroup 0: all narrow
+    wide[256:320] = True          # wave 0 of workgroup 1: all wide
+    sc[wide, 31] |= 0x80
+    pts = _random_points(ora, 91, n, "affine")
+    xy, inf = eng.multiply_vartime_batch(dev(pts), dev(sc), AFFINE, AFFINE)
+    wxy, winf = ora.multiply_batch(pts, 0, sc, 0, vartime=True)
+    bad = [i for i in range(n) if not ((host(xy)[i] == wxy[i]).all() and host(inf)[i] == winf[i])]
+    assert not bad, (bad[:10], [bool(wide[i]) for i in bad[:10]])
+    pr, pinf = eng.multiply_vartime_batch(dev(pts), dev(sc), AFFINE, PROJECTIVE)
+    wpr, wpinf = ora.multiply_batch(pts, 0, sc, 1, vartime=True)
+    assert (host(pr) == wpr).all() and (host(pinf) == wpinf).all()
+
+
 def test_torsion_and_cofactor_kats(eng, kats):
     """q * G = O through the full vartime ladder (is_torsion_free, src/curve/projective.rs:885-893, :1462);
     the reference's non-subgroup point is not killed by q but its cofactor multiple is (:1427-1433)."""
