@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CPU side of BASELINE configs 1-4: the oracle's C restatement of the reference path (kind "port": the
 reference is Rust and cannot be built in this pipeline), OpenMP static split over the box's host threads,
-on bounded samples of the same seeded workloads.  Test / measurement infrastructure only (it imports oracle/).
+on bounded samples of the same seeded workloads.  Lives under tests/ because it runs the oracle (test infrastructure); pytest does not collect it.
 Inputs that need curve points are produced by the oracle itself (no GPU needed)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
