@@ -57,9 +57,11 @@ CH_DEV u64 fp_double(u64 a) { return fp_add(a, a); }     // src/fp.rs:145-150
 // as carries (+ eps: low word - 1, high word + 1 less the low word's borrow): 6 VALU + 2 SALU
 // per element.  The three chains are interleaved stage by stage so that two VALU
 // instructions always separate the write of a carry mask from the carry-in that reads it
-// (the two wait states gfx950 needs; the compiler pads its own code with s_nop).
+// (the two wait states gfx950 needs; the compiler pads its own code with s_nop).  The in/out operands are
+// early-clobber: they are written while b operands of the other chains are still to be read, so no b operand
+// may share a register with them (it could when both hold the same value, e.g. a shared constant 0).
 #define CH_LIN3_OPERANDS                                                                                             \
-    : [l0] "+v"(l0), [h0] "+v"(h0), [l1] "+v"(l1), [h1] "+v"(h1), [l2] "+v"(l2), [h2] "+v"(h2), [s0] "=&s"(s0),      \
+    : [l0] "+&v"(l0), [h0] "+&v"(h0), [l1] "+&v"(l1), [h1] "+&v"(h1), [l2] "+&v"(l2), [h2] "+&v"(h2), [s0] "=&s"(s0), \
       [u0] "=&s"(u0), [s1] "=&s"(s1), [u1] "=&s"(u1), [s2] "=&s"(s2), [u2] "=&s"(u2)                                 \
     : [bl0] "v"(lo32(b0)), [bh0] "v"(hi32(b0)), [bl1] "v"(lo32(b1)), [bh1] "v"(hi32(b1)), [bl2] "v"(lo32(b2)),       \
       [bh2] "v"(hi32(b2))                                                                                            \
@@ -201,7 +203,7 @@ struct Acc3 {
             "v_addc_co_u32 %[t0], %[s0], 0, %[t0], %[s0]\n\t"
             "v_addc_co_u32 %[t2], %[s2], 0, %[t2], %[s2]\n\t"
             "v_addc_co_u32 %[t1], %[s1], 0, %[t1], %[s1]"
-            : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2),
+            : [c0] "+&v"(c0), [c1] "+&v"(c1), [c2] "+&v"(c2), [t0] "+&v"(t0), [t1] "+&v"(t1), [t2] "+&v"(t2),
               [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
             : [al] "v"(lo32(a)), [ah] "v"(hi32(a)), [bl] "v"(lo32(b)), [bh] "v"(hi32(b)));
     }
