@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="all-gather chunks per rank (0: 1 at N=1, 8 otherwise)")
     ap.add_argument("--cpu-sample-log2", type=int, default=14, help="CPU baseline sample = 2^k multiplications per core")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reserve-cus", type=int, default=8, help="CUs left free for the RCCL kernel when --gpus > 1")
     return ap.parse_args()
 
 
@@ -88,6 +89,10 @@ def main():
     from cheetah_amd.distributed import shard_plan, sharded_apply
 
     eng = Engine(local_rank)
+    if world > 1:
+        # the all-gather of chunk c runs while chunk c + 1 computes: keep a few CUs' worth of workgroup slots free so
+        # that RCCL's kernel is placed at once instead of waiting for (and then delaying) a persistent compute launch
+        eng.set_reserved_cus(args.reserve_cus)
     n = 1 << args.log2n
     chunks = args.chunks or (1 if world == 1 else 8)
     s, plan = shard_plan(n, world, chunks)

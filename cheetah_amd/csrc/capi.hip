@@ -24,6 +24,7 @@ struct cheetah_ctx {
     u64* scratch = nullptr;
     size_t scratch_words = 0;
     int num_cus = 0;
+    int reserved_cus = 0;  // CUs' worth of workgroup slots the persistent launches leave free (cheetah_ctx_set_reserved_cus)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     std::string err;
 };
@@ -175,7 +176,7 @@ extern "C" int32_t cheetah_ctx_synchronize(cheetah_ctx* ctx) {
 // work needs.  The kernels grid-stride over the rest.
 static int lane_grid(const cheetah_ctx* ctx, size_t n_lanes_needed, int blocks_per_cu) {
     size_t want = (n_lanes_needed + BLOCK - 1) / BLOCK;
-    size_t cap = (size_t)ctx->num_cus * blocks_per_cu;
+    size_t cap = (size_t)(ctx->num_cus - ctx->reserved_cus) * blocks_per_cu;
     size_t g = want < cap ? want : cap;
     return g ? (int)g : 1;
 }
@@ -277,7 +278,8 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
     if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     if (out_form == CHEETAH_AFFINE) {  // affine results: the widened comb (one 1 024-thread workgroup per CU)
         size_t want = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
-        int grid_w = (int)(want < (size_t)ctx->num_cus ? want : (size_t)ctx->num_cus);
+        const size_t cus_w = (size_t)(ctx->num_cus - ctx->reserved_cus);
+        int grid_w = (int)(want < cus_w ? want : cus_w);
         const size_t per_launch_w = (size_t)grid_w * WIDE_BLOCK * ROUNDS_PER_LAUNCH * 4;
         for (size_t off = 0; off < n; off += per_launch_w) {
             const size_t cnt = n - off < per_launch_w ? n - off : per_launch_w;
@@ -919,6 +921,12 @@ extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t
     return CHEETAH_OK;
 }
 
+extern "C" int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx* ctx, int cus) {
+    CHECK_CTX(ctx);
+    if (cus < 0 || cus >= ctx->num_cus) return fail(ctx, CHEETAH_ERR_INVALID, "reserved CUs must be in [0, number of CUs)");
+    ctx->reserved_cus = cus;
+    return CHEETAH_OK;
+}
 extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n, int vartime, int out_form, size_t* units) {
     CHECK_CTX(ctx);
     if (!units) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");

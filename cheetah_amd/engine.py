@@ -402,6 +402,11 @@ class Engine:
         self._check(self._lib.cheetah_calibrate_mad_peak(self._h, C.byref(v)))
         return v.value
 
+    def set_reserved_cus(self, cus):
+        """Leave `cus` CUs' worth of workgroup slots free in the persistent launches (room for an RCCL kernel on
+        another stream); 0 = none."""
+        self._check(self._lib.cheetah_ctx_set_reserved_cus(self._h, int(cus)))
+
     def multiply_units_per_launch(self, n, vartime=False, out_form=AFFINE):
         """Scalar multiplications per kernel launch for a batch of n (the library bounds each launch)."""
         v = C.c_size_t()

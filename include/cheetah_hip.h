@@ -61,6 +61,12 @@ int32_t cheetah_ctx_destroy(cheetah_ctx *ctx);
 int32_t cheetah_ctx_set_stream(cheetah_ctx *ctx, void *hip_stream);
 int32_t cheetah_ctx_use_own_stream(cheetah_ctx *ctx);
 int32_t cheetah_ctx_synchronize(cheetah_ctx *ctx);
+/* The ladder, fixed-base and normalize kernels are persistent: a launch fills every CU with as many workgroups as
+ * fit and keeps them for the whole launch, so a kernel on another stream (an RCCL collective returning the previous
+ * chunk's results) finds no free slot until a launch ends.  Reserving `cus` CUs' worth of slots (0 = none, the
+ * default) sizes those launches smaller, so that such a kernel can always be placed.  No counterpart in the
+ * reference (it has neither streams nor collectives); used by the multi-GPU path. */
+int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx *ctx, int cus);
 const char *cheetah_last_error(const cheetah_ctx *ctx); /* ctx may be NULL: last create error */
 const char *cheetah_version(void);
 

@@ -527,6 +527,29 @@ def test_multiply_vartime_mixed_wide_scalars(eng, ora):
     assert (host(pr) == wpr).all() and (host(pinf) == wpinf).all()
 
 
+def test_reserved_cus_same_results(eng, ora):
+    """cheetah_ctx_set_reserved_cus only sizes the persistent launches smaller (room for an RCCL kernel on another
+    stream): same results, fewer units per launch; out-of-range values are rejected."""
+    from cheetah_amd import AFFINE, CheetahError
+    n = 3000
+    sc = synth.scalars(12, n)
+    pts, _ = eng.mul_by_generator_batch(dev(sc), AFFINE)
+    k = dev(synth.scalars(13, n))
+    full = eng.multiply_units_per_launch(1 << 26)
+    a0, i0 = eng.multiply_batch(pts, k, AFFINE, AFFINE)
+    try:
+        eng.set_reserved_cus(8)
+        assert eng.multiply_units_per_launch(1 << 26) < full
+        a1, i1 = eng.multiply_batch(pts, k, AFFINE, AFFINE)
+        g1, _ = eng.mul_by_generator_batch(dev(sc), AFFINE)
+        with pytest.raises(CheetahError):
+            eng.set_reserved_cus(100000)
+    finally:
+        eng.set_reserved_cus(0)
+    assert (host(a0) == host(a1)).all() and (host(i0) == host(i1)).all() and (host(g1) == host(pts)).all()
+    assert eng.multiply_units_per_launch(1 << 26) == full
+
+
 def test_torsion_and_cofactor_kats(eng, kats):
     """q * G = O through the full vartime ladder (is_torsion_free, src/curve/projective.rs:885-893, :1462);
     the reference's non-subgroup point is not killed by q but its cofactor multiple is (:1427-1433)."""
