@@ -11,7 +11,7 @@
 #pragma once
 #include "fp.hip.h"
 
-// Fp6 mul / square are ~450 / ~350 instructions each.  Inlined into every point
+// Fp6 mul / square are 410 / 305 VALU instructions each.  Inlined into every point
 // formula the ladder loop would exceed the instruction cache, so by default they
 // are real functions.  Their arguments and result cross the call as 6 x u64
 // vectors: hipcc passes those in VGPRs, whereas a second struct argument goes
