@@ -4,27 +4,37 @@ multiplications per second, plus Fp6 multiplications per second.
 
     python bench.py --gpus N --steps K --warmup W
 
+With --gpus N > 1 and no WORLD_SIZE in the environment this process is only a
+launcher: before anything touches the GPU it starts the N rank processes as
+fresh children (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...` of this same file), forwards rank 0's JSON line and
+exits with the children's status.  Started by torch.distributed.run itself
+(WORLD_SIZE set) it is one of the ranks.
+
 Workload (BASELINE config 5): 2^26 seeded (P_i, k_i) pairs, out[i] = k_i * P_i by
 AffinePoint::multiply (src/curve/affine.rs:373-375 -> JacobianPoint::multiply,
-src/curve/jacobian.rs:599-611), affine results.  The
-2^26 pairs are sharded over the N ranks (strong scaling: the total is fixed) and
-the affine results are all-gathered over RCCL so that every rank holds all of
-them.  Inputs are synthetic, generated on the device (points r_i * G, seeded
-scalars) before the timed region; a step is one full pass.  One JSON line on
-stdout from rank 0.
+src/curve/jacobian.rs:599-611), affine results.  The 2^26 pairs are sharded over
+the N ranks (strong scaling: the total is fixed) and the affine results are
+all-gathered over RCCL so that every rank holds all of them.  Inputs are
+synthetic, generated on the device (points r_i * G, seeded scalars) before the
+timed region; a step is one full pass.  One JSON line on stdout from rank 0.
+
+--rehearse-cpu runs the SAME launcher, sharding, all-gather and JSON plumbing on
+CPU over gloo with a stand-in for the arithmetic (a function of the global
+index): a rehearsal of the multi-process path for boxes without GPUs
+(tests/test_bench_launcher_cpu.py).  Its line says so and is not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 # reference-algorithm work per unit (SURVEY.md 8d / BASELINE.md 2; derivation in DESIGN.md 5).
 # Affine in / affine out is AffinePoint::multiply, which runs JacobianPoint::multiply
@@ -35,7 +45,29 @@ FPMUL_PER_CT_MULT = 72588
 MAD32_PER_CT_MULT = 4 * FPMUL_PER_CT_MULT   # 1 Fp mul = 4 v_mad_u64_u32 on 32-bit limbs
 MAD32_PER_CT_MULT_PROJECTIVE = 348468       # ProjectivePoint::multiply, for comparison only
 FP6_MUL_BYTES = 144             # 2 x 48 in + 48 out
+BN_JAC_BYTES = 241              # 144 in + 96 + 1 out
+BN_JAC_MAD32 = 660              # 165 Fp mul per point (6 M + 1 S), the chunk's inversion not credited
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
+
+
+def ceiling_model():
+    """Minimal VALU issue slots of THIS formulation per scalar multiplication: what the
+    kernel would issue if every Fp6 operation ran at its floor and nothing else were executed.
+      Fp6 mul    = 36 products x (4 mad + 4 carry counts) + 6 reductions x 14 + 5 scalings by 7 x 9 = 417
+      Fp6 square = 21 x 8 + 6 x 14 + 5 x 9 + 5 doublings x 6                                         = 327
+      Fp6 add / sub / double = 36 (6 VALU per coefficient on carry masks)
+    Per window: 4 doublings (4 M + 4 S, the last without its z4 product) + 1 mixed addition (8 M + 5 S),
+    ~8 linear operations each; 64 windows; the table (8 entries) and the two inversions ~ 60 k slots.
+    ceiling_frac = credited mad32 / those slots: the fraction this formulation could reach if the
+    SIMDs issued one of its instructions in every mad slot."""
+    M, S, L = 417, 327, 36
+    dbl = 4 * M + 4 * S + 8 * L
+    scan = 8 * 24                                  # constant-time lookup: one select per 32-bit word of 8 entries
+    add = 8 * M + 5 * S + 8 * L + scan
+    window = 4 * dbl - M + add
+    table_and_inversions = 60000
+    slots = 64 * window + table_and_inversions
+    return {"min_issue_slots_per_unit": slots, "ceiling_frac": MAD32_PER_CT_MULT / slots}
 
 
 def parse():
@@ -47,13 +79,59 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="all-gather chunks per rank (0: 1 at N=1, 8 otherwise)")
     ap.add_argument("--cpu-sample-log2", type=int, default=14, help="CPU baseline sample = 2^k multiplications per core")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reserve-cus", type=int, default=8, help="CUs left free for the RCCL kernel when --gpus > 1")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Fp6 / batch_normalize roofline measurements")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="CUs' worth of workgroup slots the persistent launches leave free for the RCCL kernel (--gpus > 1)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="gloo on CPU with a stand-in for the arithmetic: launcher / sharding / gather rehearsal, not a measurement")
     return ap.parse_args()
 
+
+# ------------------------------------------------------------------ launcher -----
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """Parent of a multi-GPU run: starts the rank processes and forwards rank 0's line.  Nothing here
+    initialises the GPU (torch.cuda.device_count() does not), so the children are the first to."""
+    if not args.rehearse_cpu:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, ndev))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if p.returncode != 0:
+        sys.stderr.write("bench.py: a rank failed (torch.distributed.run exit %d)\n" % p.returncode)
+        return p.returncode or 1
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+# --------------------------------------------------------------- CPU baseline -----
 
 def cpu_baseline(n_sample, seed=5):
     """The oracle (C restatement of the reference CPU path, OpenMP over independent
     elements) timed on this box's host cores on a bounded sample of the same workload."""
+    import numpy as np
     from cheetah_amd import synth
     from oracle import binding as ora
     ora.build()
@@ -72,26 +150,152 @@ def cpu_baseline(n_sample, seed=5):
                       "OpenMP static split over %d threads), best of 2" % (int(np.log2(n_sample)), cores)}
 
 
+# ------------------------------------------------------------------- one rank -----
+
+def rehearse(args, world, rank):
+    """gloo / CPU rehearsal: same plan, same sharded_apply, same line; the 'arithmetic' is a stand-in."""
+    import torch
+    import torch.distributed as dist
+    from cheetah_amd.distributed import sharded_apply
+    if world > 1:
+        dist.init_process_group("gloo")
+    n = 1 << args.log2n
+    chunks = args.chunks or (1 if world == 1 else 8)
+
+    def compute(g0, cnt, oxy, oinf):
+        idx = torch.arange(g0, g0 + cnt, dtype=torch.int64)
+        oxy.copy_(idx[:, None] * 12 + torch.arange(12, dtype=torch.int64)[None, :])
+        oinf.copy_((idx % 5 == 0).to(torch.uint8))
+
+    for _ in range(args.warmup):
+        sharded_apply(compute, n, 12, rank, world, chunks, "cpu")
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        xy, inf = sharded_apply(compute, n, 12, rank, world, chunks, "cpu")
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ones = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.all_reduce(ones)
+    want = torch.arange(n * 12, dtype=torch.int64).reshape(n, 12)
+    ok = bool(torch.equal(xy, want)) and int(inf.sum()) == len(range(0, n, 5))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Cheetah variable-base scalar mults/sec (1 GPU, node) + Fp6 muls/sec", "value": n * args.steps / dt,
+            "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "REHEARSAL on CPU over gloo: stand-in for the arithmetic, not a measurement",
+            "rehearsal": True, "ranks_seen": int(ones.item()), "gathered_ok": ok,
+            "checksum": "%016x" % (int(xy.sum().item()) & 0xFFFFFFFFFFFFFFFF),
+            "config": {"workload": "launcher / sharding / all-gather rehearsal", "n": n, "per_gpu": n // world,
+                       "allgather_chunks": chunks, "parallelism": "shard%d" % world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def secondary_rooflines(eng, torch):
+    """Config 1 (elementwise Fp6 multiplication) and config 4 (batch_normalize, 2^24 Jacobian points):
+    HIP events on the launch stream, one GPU."""
+    from cheetah_amd import AFFINE, JACOBIAN
+    out = {}
+
+    def timed(f, reps):
+        f()
+        torch.cuda.synchronize()
+        eng._use_torch_stream()
+        eng.timer_start()
+        for _ in range(reps):
+            f()
+        return eng.timer_stop_ms() / reps
+
+    # config 1 as BASELINE.json sizes it: 2^20 pairs = 151 MB, which stays in the 256 MB Infinity Cache between
+    # repetitions -- NOT an HBM figure
+    nf = 1 << 20
+    fa, fb = eng.synth_fp6(1, nf, 0), eng.synth_fp6(1, nf, nf)
+    ms20 = timed(lambda: eng.fp6_mul_batch(fa, fb), 20)
+    out["fp6_muls_per_s"] = nf / (ms20 * 1e-3)
+    out["fp6_mul_2p20_infinity_cache_resident"] = {"ms_per_launch": ms20, "GBps": nf * FP6_MUL_BYTES / (ms20 * 1e-3) / 1e9,
+                                                   "note": "151 MB working set re-run back to back: served by the 256 MB Infinity Cache"}
+    del fa, fb
+    # the HBM-bound figure: 2^24 pairs = 2.4 GB per launch, nothing survives in a cache from one launch to the next
+    nc = 1 << 24
+    ca, cb = eng.synth_fp6(1, nc, 0), eng.synth_fp6(1, nc, nc)
+    msc = timed(lambda: eng.fp6_mul_batch(ca, cb), 5)
+    gbs = nc * FP6_MUL_BYTES / (msc * 1e-3) / 1e9
+    out["fp6_muls_per_s_cold_2p24"] = nc / (msc * 1e-3)
+    out["roofline_fp6_mul"] = {"bound": "hbm", "kernel": "k_fp6_elementwise<mul>", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": msc,
+                               "units_per_launch": nc, "bytes_per_unit": FP6_MUL_BYTES,
+                               "note": "cold: 2^24 pairs (2.4 GB per launch, 9x the Infinity Cache)"}
+    del ca, cb
+    # config 4: 2^24 Jacobian points (x l^2, y l^3, l) from k_i G, an identity every 1000
+    nb = 1 << 24
+    aff, _ = eng.mul_by_generator_batch(eng.synth_scalars(4, nb), AFFINE)
+    lam = eng.synth_fp6(4, nb)
+    l2 = eng.fp6_square_batch(lam)
+    l3 = eng.fp6_mul_batch(l2, lam)
+    affi = aff.view(torch.int64)
+    x = eng.fp6_mul_batch(affi[:, 0:6].contiguous(), l2)
+    y = eng.fp6_mul_batch(affi[:, 6:12].contiguous(), l3)
+    jac = torch.cat([x.view(torch.int64), y.view(torch.int64), lam.view(torch.int64)], dim=1).contiguous()
+    del x, y, l2, l3, lam
+    jac[torch.arange(0, nb, 1000, device=jac.device), 12:18] = 0
+    msb = timed(lambda: eng.batch_normalize(jac, JACOBIAN), 5)
+    xy, inf = eng.batch_normalize(jac, JACOBIAN)
+    want = affi.clone()
+    want[torch.arange(0, nb, 1000, device=jac.device)] = torch.tensor([0] * 6 + [1] + [0] * 5, dtype=torch.int64, device=jac.device)
+    bn_ok = bool(torch.equal(xy.view(torch.int64), want)) and int(inf.sum()) == len(range(0, nb, 1000))
+    mad_peak = eng.calibrate_mad_peak()
+    ach = nb * BN_JAC_MAD32 / (msb * 1e-3) / 1e12
+    out["batch_normalize_points_per_s"] = nb / (msb * 1e-3)
+    out["roofline_batch_normalize"] = {"bound": "valu", "kernel": "k_batch_normalize<jacobian>", "achieved": ach, "peak": mad_peak,
+                                       "unit": "Tmad32/s", "frac": ach / mad_peak, "traffic": None, "ms_per_launch": msb,
+                                       "units_per_launch": nb, "mad32_per_unit": BN_JAC_MAD32,
+                                       "hbm_GBps": nb * BN_JAC_BYTES / (msb * 1e-3) / 1e9, "hbm_frac": nb * BN_JAC_BYTES / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "round_trip_ok": bn_ok,
+                                       "note": "config 4: 2^24 Jacobian points, identities included; output compared in full with the affine points they were built from"}
+    return out
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.rehearse_cpu:
+        sys.exit(rehearse(args, world, rank))
+
+    import torch
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: no GPU %d (visible: %d)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        # the collective's kernel runs on ProcessGroupNCCL's own stream: ask for that one to be high priority
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            dist.init_process_group("nccl", device_id=torch.device(device), pg_options=opts)
+        except (AttributeError, TypeError):
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     from cheetah_amd import AFFINE, Engine
     from cheetah_amd.distributed import shard_plan, sharded_apply
 
     eng = Engine(local_rank)
-    if world > 1:
-        # the all-gather of chunk c runs while chunk c + 1 computes: keep a few CUs' worth of workgroup slots free so
-        # that RCCL's kernel is placed at once instead of waiting for (and then delaying) a persistent compute launch
+    if world > 1 and args.reserve_cus:
         eng.set_reserved_cus(args.reserve_cus)
     n = 1 << args.log2n
     chunks = args.chunks or (1 if world == 1 else 8)
@@ -109,29 +313,39 @@ def main():
         del r
     torch.cuda.synchronize()
     local_of = {g0: j for j, (c, g0) in enumerate(plan[rank])}
-    def step(timed_kernel=False):
-        if timed_kernel:  # one un-overlapped pass, HIP events on the launch stream around each call's kernel launches
-            total = 0.0
-            launches = 0
-            xy = torch.empty((s, 12), dtype=torch.int64, device=device)
-            inf = torch.empty((s,), dtype=torch.uint8, device=device)
-            upl = eng.multiply_units_per_launch(s, False, AFFINE)  # the library bounds each k_multiply_ct launch
-            for j in range(chunks):
-                eng._use_torch_stream()
-                eng.timer_start()
-                eng.multiply_batch(pts[j * s:(j + 1) * s], ks[j * s:(j + 1) * s], AFFINE, AFFINE, out=xy, inf=inf)
-                total += eng.timer_stop_ms()
-                launches += -(-s // upl)
-            return total / launches, chunks * s / launches, launches
-        return sharded_apply(lambda g0, cnt, oxy, oinf: eng.multiply_batch(pts[local_of[g0] * s:(local_of[g0] + 1) * s],
-                                                                           ks[local_of[g0] * s:(local_of[g0] + 1) * s],
-                                                                           AFFINE, AFFINE, out=oxy, inf=oinf),
-                             n, 12, rank, world, chunks, device)
+
+    def compute(g0, cnt, oxy, oinf):
+        j = local_of[g0]
+        eng.multiply_batch(pts[j * s:(j + 1) * s], ks[j * s:(j + 1) * s], AFFINE, AFFINE, out=oxy, inf=oinf)
+
+    def step(gather=True):
+        return sharded_apply(compute, n, 12, rank, world, chunks, device, gather=gather)
+
+    def timed_kernel_pass():
+        # one un-overlapped pass, HIP events on the launch stream around each call's kernel launches
+        total, launches = 0.0, 0
+        xy = torch.empty((s, 12), dtype=torch.int64, device=device)
+        inf = torch.empty((s,), dtype=torch.uint8, device=device)
+        upl = eng.multiply_units_per_launch(s, False, AFFINE)  # the library bounds each k_multiply_ct launch
+        for j in range(chunks):
+            eng._use_torch_stream()
+            eng.timer_start()
+            eng.multiply_batch(pts[j * s:(j + 1) * s], ks[j * s:(j + 1) * s], AFFINE, AFFINE, out=xy, inf=inf)
+            total += eng.timer_stop_ms()
+            launches += -(-s // upl)
+        return total / launches, chunks * s / launches, launches
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         out = step()
@@ -141,44 +355,45 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     xy, inf = out
     checksum = int(xy.sum().item()) & 0xFFFFFFFFFFFFFFFF  # wrap-around sum of canonical limbs, identical on every N
     n_inf = int(inf.sum().item())
+    del out, xy, inf
+
+    # ---- what the gather costs: the same pass without it (this rank's blocks only) --------
+    ones = torch.ones(1, dtype=torch.int64, device=device)
+    compute_ms = None
+    if world > 1:
+        dist.all_reduce(ones)                     # ranks_seen: a sum of ones over RCCL
+        barrier()
+        t0 = time.perf_counter()
+        o = step(gather=False)
+        barrier()
+        compute_ms = max_over_ranks(time.perf_counter() - t0) * 1e3
+        del o
 
     # ---- roofline of the dominant kernel (k_multiply_ct), measured live ---------
-    ms_launch, units_per_launch, n_launches = step(timed_kernel=True)   # averages over the pass's kernel launches
+    ms_launch, units_per_launch, n_launches = timed_kernel_pass()   # averages over the pass's kernel launches
     mad_peak = eng.calibrate_mad_peak()          # T v_mad_u64_u32 / s, measured on this device
     achieved = units_per_launch * MAD32_PER_CT_MULT / (ms_launch * 1e-3) / 1e12
     traffic = None                               # HBM bytes per launch from the committed PMC passes (profiles/)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tr = json.load(f)["k_multiply_ct"]
-        traffic = (tr["fetch_bytes_per_unit"] + tr["write_bytes_per_unit"]) * units_per_launch
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tr = json.load(f)["k_multiply_ct"]
+            traffic = (tr["fetch_bytes_per_unit"] + tr["write_bytes_per_unit"]) * units_per_launch
+            break
+        except (OSError, KeyError, ValueError):
+            pass
 
-    # ---- secondary metric: elementwise Fp6 multiplication (config 1, 2^20 pairs) --
-    nf = 1 << 20
-    fa, fb = eng.synth_fp6(1, nf, 0), eng.synth_fp6(1, nf, nf)
-    for _ in range(3):
-        eng.fp6_mul_batch(fa, fb)
-    torch.cuda.synchronize()
-    eng._use_torch_stream()
-    reps = 20
-    eng.timer_start()
-    for _ in range(reps):
-        eng.fp6_mul_batch(fa, fb)
-    fp6_ms = eng.timer_stop_ms() / reps
-    fp6_rate = nf / (fp6_ms * 1e-3)
-    fp6_gbs = nf * FP6_MUL_BYTES / (fp6_ms * 1e-3) / 1e9
+    secondary = {}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_rooflines(eng, torch)
 
     if rank == 0:
         total = n * args.steps
+        ceil = ceiling_model()
         line = {
             "metric": "Cheetah variable-base scalar mults/sec (1 GPU, node) + Fp6 muls/sec",
             "value": total / dt,
@@ -194,25 +409,29 @@ def main():
             "data": "synthetic",
             "config": {"workload": "2^%d variable-base constant-time scalar mults (AffinePoint::multiply = JacobianPoint::multiply ladder), affine in/out, "
                                    "sharded over %d GPU(s), RCCL all-gather of results (BASELINE config 5)" % (args.log2n, world),
-                       "n": n, "per_gpu": n // world, "allgather_chunks": chunks, "parallelism": "shard%d" % world},
-            "fp6_muls_per_s": fp6_rate,
+                       "n": n, "per_gpu": n // world, "allgather_chunks": chunks, "parallelism": "shard%d" % world,
+                       "reserved_cus": args.reserve_cus if world > 1 else 0},
             "checksum": "%016x" % checksum,
             "identities": n_inf,
+            "ranks_seen": int(ones.item()),
             "roofline": {"bound": "valu", "kernel": "k_multiply_ct", "achieved": achieved, "peak": mad_peak,
                          "unit": "Tmad32/s", "frac": achieved / mad_peak, "traffic": traffic,
                          "ms_per_launch": ms_launch, "units_per_launch": units_per_launch, "launches_per_pass": n_launches,
                          "mad32_per_unit": MAD32_PER_CT_MULT,
+                         "ceiling_frac": ceil["ceiling_frac"], "min_issue_slots_per_unit": ceil["min_issue_slots_per_unit"],
                          "frac_if_credited_as_ProjectivePoint_multiply": achieved * MAD32_PER_CT_MULT_PROJECTIVE / MAD32_PER_CT_MULT / mad_peak,
                          "note": "achieved = reference-algorithm mad32 count of AffinePoint::multiply (72588 Fp mul x 4) x units / "
                                  "HIP-event launch time; peak = v_mad_u64_u32 issue rate measured live on this device; the kernel "
                                  "is VALU-issue bound (profiles/, DESIGN.md 5): carries and reductions issue at the same rate as the mads; "
+                                 "ceiling_frac = credited mad32 / minimal issue slots of this formulation (bench.py ceiling_model, DESIGN.md 5); "
                                  "ms_per_launch / units_per_launch are per k_multiply_ct kernel launch (the library bounds each launch); "
                                  "traffic = (FETCH_SIZE + WRITE_SIZE) per unit from the rocprofv3 PMC passes in profiles/ x units_per_launch: "
                                  "the lane's window table is re-read in each of the 64 windows (algorithmic bytes: 225 per unit)"},
-            "roofline_fp6_mul": {"bound": "hbm", "kernel": "k_fp6_elementwise<mul>", "achieved": fp6_gbs, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": fp6_gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": fp6_ms,
-                                 "units_per_launch": nf, "bytes_per_unit": FP6_MUL_BYTES},
         }
+        if compute_ms is not None:
+            line["compute_ms"] = compute_ms
+            line["gather_ms_exposed"] = dt / args.steps * 1e3 - compute_ms
+        line.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))

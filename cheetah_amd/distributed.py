@@ -14,11 +14,16 @@ of the result and needs no staging copy):
     rank r computes, for every chunk c, the s consecutive elements starting at
     c * (n / C) + r * s; the all-gather of chunk c fills [c * n / C, (c + 1) * n / C).
 
-Chunk c's all-gather runs on a second, high-priority stream while chunk c + 1
-computes; only the last chunk's gather (1 / C of the traffic) is exposed.  The
-ladder kernels fill every CU with persistent workgroups, so the library bounds
-each launch to two rounds of the resident grid (~10 ms): a collective's
-workgroups get CU slots at the next launch boundary at the latest.
+Chunk c's all-gather is enqueued from a second stream while chunk c + 1
+computes; only the last chunk's gather (1 / C of the traffic) is exposed.
+ProcessGroupNCCL runs the collective's kernel on a stream of its own that waits
+for the enqueuing stream; whether that stream is high priority is a property of
+the process group (bench.py asks for it with is_high_priority_stream), not of
+the stream used here.  The ladder kernels fill every CU with persistent
+workgroups, so the library bounds each launch to two rounds of the resident grid
+(18 ms measured at 2^19 multiplications): a collective's workgroups get CU slots
+at the next launch boundary at the latest, and nothing computes after the last
+chunk, so the exposed gather is the last chunk's own duration.
 """
 import torch
 import torch.distributed as dist
@@ -45,9 +50,8 @@ def sharded_apply(compute, n, width, rank, world, chunks, device, dtype=torch.in
     xy = torch.empty((n, width), dtype=dtype, device=device)
     inf = torch.empty((n,), dtype=torch.uint8, device=device)
     use_cuda = torch.device(device).type == "cuda"
-    # high priority: the gather's workgroups take the CU slots a finishing compute launch frees
-    # before the next compute launch does (the ladder launches are bounded to ~10 ms for this)
-    comm = torch.cuda.Stream(device=device, priority=-1) if (use_cuda and world > 1 and gather) else None
+    # a side stream orders "gather chunk c after its compute" without holding back chunk c + 1's launches
+    comm = torch.cuda.Stream(device=device) if (use_cuda and world > 1 and gather) else None
     main = torch.cuda.current_stream(device) if use_cuda else None
     for c, g0 in plan[rank]:
         compute(g0, s, xy[g0:g0 + s], inf[g0:g0 + s])
