@@ -44,6 +44,7 @@ SIGNATURES = {
     "cheetah_multiply_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
     "cheetah_multiply_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
     "cheetah_multiply_vartime_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_multiply_batch_dev_noalloc": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),
     "cheetah_multiply_many_batch": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _i]),
     "cheetah_multiply_many_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _i]),
     "cheetah_multiply_double_with_basepoint_vartime_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i]),

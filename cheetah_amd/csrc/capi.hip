@@ -15,6 +15,16 @@
 
 using namespace cheetah;
 
+// ---- the allocation-free entry point's arena (cheetah_multiply_batch_dev_noalloc) ----------------------
+// A file-scope device array instead of the context's hipMalloc'ed scratch: window tables for
+// NOALLOC_MAX_BLOCKS workgroups of k_multiply_ct (96 MiB; every GPU the library runs on holds its own
+// copy until the process ends).  In host code the array's NAME is only a handle: its device address is
+// taken once per device with hipGetSymbolAddress at context creation (cheetah_ctx::noalloc_arena) and
+// only that pointer is ever passed to a kernel.
+constexpr int NOALLOC_MAX_BLOCKS = 128;
+constexpr size_t NOALLOC_WORDS = (size_t)NOALLOC_MAX_BLOCKS * LaneScratch::WORDS_PER_BLOCK;
+static __device__ __align__(256) u64 noalloc_scratch[NOALLOC_WORDS];
+
 struct cheetah_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
@@ -23,6 +33,7 @@ struct cheetah_ctx {
     u8* fixed_scalars = nullptr;  // q | cofactor, 64 bytes (is_torsion_free / clear_cofactor)
     u64* scratch = nullptr;
     size_t scratch_words = 0;
+    u64* noalloc_arena = nullptr;  // this device's address of noalloc_scratch (hipGetSymbolAddress, once, at creation)
     int num_cus = 0;
     int reserved_cus = 0;  // CUs' worth of workgroup slots the persistent launches leave free (cheetah_ctx_set_reserved_cus)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
@@ -109,6 +120,7 @@ extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
     CREATE_TRY(hipEventCreate(&ctx->ev0));
     CREATE_TRY(hipEventCreate(&ctx->ev1));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    CREATE_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ctx->noalloc_arena), HIP_SYMBOL(noalloc_scratch)));
     CREATE_TRY(hipMalloc(&ctx->tables, sizeof(DeviceTables)));
     CREATE_TRY(hipMalloc(&ctx->fixed_scalars, 64));
     CREATE_TRY(hipMemcpyAsync(ctx->fixed_scalars, FQ_MODULUS_BYTES, 32, hipMemcpyHostToDevice, ctx->stream));
@@ -308,9 +320,11 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
     return CHEETAH_OK;
 }
 
+// arena == nullptr: the context's own scratch (grown on demand); otherwise a caller-chosen arena that holds
+// max_blocks workgroups' tables, and the grids are capped to it (the kernels grid-stride over the rest).
 template <bool VARTIME>
 static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
-                            int out_form) {
+                            int out_form, u64* arena = nullptr, int max_blocks = 0) {
     CHECK_CTX(ctx);
     if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
     if (n == 0) return CHEETAH_OK;
@@ -320,9 +334,15 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
     // for every wave whose scalars are all below 2^255, then the reference's NAF ladder for the remaining waves.
     const bool direct = VARTIME && out_form == CHEETAH_AFFINE;
     // the ONLY_WIDE instance of the NAF kernel (normally nothing to do) is compiled for 2 waves: no scratch
-    const int grid_vt = lane_grid(ctx, n, direct ? 2 : CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
+    int grid_vt = lane_grid(ctx, n, direct ? 2 : CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
+    if (arena) {
+        if (grid_vt > max_blocks) grid_vt = max_blocks;
+        if (grid_ct > max_blocks) grid_ct = max_blocks;
+    } else {
+        if (int32_t rc = ensure_scratch(ctx, (size_t)(grid_vt > grid_ct ? grid_vt : grid_ct) * LaneScratch::WORDS_PER_BLOCK)) return rc;
+        arena = ctx->scratch;
+    }
     const int grid = (VARTIME && !direct) ? grid_vt : grid_ct;
-    if (int32_t rc = ensure_scratch(ctx, (size_t)(grid_vt > grid_ct ? grid_vt : grid_ct) * LaneScratch::WORDS_PER_BLOCK)) return rc;
     // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (~25 ms of
     // work).  The workgroups are persistent within a launch and fill every CU, so a kernel
     // on another stream (the RCCL all-gather of the previous chunk) can only get CU slots
@@ -339,15 +359,15 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
     do {                                                                                                                       \
         if constexpr (VARTIME && O == 0) {                                                                                             \
             hipLaunchKernelGGL((k_multiply_ct<A, I, O, true>), dim3(grid_ct), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,  \
-                               sc_o, out_o, inf_o, cnt, ctx->scratch);                                                         \
+                               sc_o, out_o, inf_o, cnt, arena);                                                         \
             hipLaunchKernelGGL((k_multiply_vartime<A, I, O, true>), dim3(grid_vt), dim3(BLOCK), 0, ctx->stream, ctx->tables,    \
-                               pts_o, sc_o, out_o, inf_o, cnt, ctx->scratch, 0);                                               \
+                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                               \
         } else if constexpr (VARTIME)                                                                                              \
             hipLaunchKernelGGL((k_multiply_vartime<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,      \
-                               pts_o, sc_o, out_o, inf_o, cnt, ctx->scratch, 0);                                               \
+                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                               \
         else                                                                                                                   \
             hipLaunchKernelGGL((k_multiply_ct<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,    \
-                               sc_o, out_o, inf_o, cnt, ctx->scratch);                                                         \
+                               sc_o, out_o, inf_o, cnt, arena);                                                         \
     } while (0)
 #define DISPATCH(KERN)                                         \
     switch (in_form * 3 + out_form) {                          \
@@ -374,6 +394,17 @@ extern "C" int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx* ctx, const ui
                                                       const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
                                                       int out_form) {
     return multiply_dev<true>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+}
+// cheetah_multiply_batch_dev for callers that cannot allocate: the same kernels on the file-scope arena.
+// Calls no hipMalloc / hipFree (nor anything else that allocates): argument checks, hipSetDevice, kernel launches.
+// The arena needs no clearing: a workgroup writes every table entry it later reads, in every round.
+extern "C" int32_t cheetah_multiply_batch_dev_noalloc(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
+                                                      uint64_t* out, uint8_t* inf, size_t n, int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (n > (size_t)CHEETAH_NOALLOC_MAX_N)
+        return fail(ctx, CHEETAH_ERR_INVALID, "cheetah_multiply_batch_dev_noalloc: n exceeds CHEETAH_NOALLOC_MAX_N (use cheetah_multiply_batch_dev)");
+    if (!ctx->noalloc_arena) return fail(ctx, CHEETAH_ERR_HIP, "the static arena's device address is not known");
+    return multiply_dev<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form, ctx->noalloc_arena, NOALLOC_MAX_BLOCKS);
 }
 
 // ------------------------------------------------- host-pointer wrappers -----

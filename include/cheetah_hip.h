@@ -141,6 +141,18 @@ int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx *ctx, const uint64_t *pts
                                            const uint8_t *scalars32, uint64_t *out, uint8_t *inf, size_t n,
                                            int out_form);
 
+/* cheetah_multiply_batch_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels
+ * and bit-identical results; the per-lane window tables live in a file-scope device array of the library (96 MiB per
+ * GPU, held until the process ends) instead of the context's hipMalloc'ed scratch, and the call makes no
+ * hipMalloc / hipFree or any other allocating call.  The arena covers 128 workgroups, so large batches run at a
+ * fraction of cheetah_multiply_batch_dev's rate; n > CHEETAH_NOALLOC_MAX_N is rejected with CHEETAH_ERR_INVALID.
+ * All calls on one GPU share that GPU's arena (contents of the previous call are simply overwritten; nothing needs
+ * clearing): two such calls that overlap in time on one GPU -- from different contexts or streams -- race. */
+#define CHEETAH_NOALLOC_MAX_N (1u << 20)
+int32_t cheetah_multiply_batch_dev_noalloc(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
+                                           uint64_t *out, uint8_t *inf, size_t n, int out_form);
+
 /* ---- multi-scalar (Straus) ladders -----------------------------------------
  * out[g] = sum_{j < m} scalars[g*m + j] * pts[g*m + j]   (points and scalars interleaved per group)
  * cheetah_multiply_many_batch          {Projective,Jacobian}Point::multiply_many
