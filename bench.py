@@ -51,23 +51,27 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
 
 
 def ceiling_model():
-    """Minimal VALU issue slots of THIS formulation per scalar multiplication: what the
-    kernel would issue if every Fp6 operation ran at its floor and nothing else were executed.
-      Fp6 mul    = 36 products x (4 mad + 4 carry counts) + 6 reductions x 14 + 5 scalings by 7 x 9 = 417
-      Fp6 square = 21 x 8 + 6 x 14 + 5 x 9 + 5 doublings x 6                                         = 327
-      Fp6 add / sub / double = 36 (6 VALU per coefficient on carry masks)
-    Per window: 4 doublings (4 M + 4 S, the last without its z4 product) + 1 mixed addition (8 M + 5 S),
-    ~8 linear operations each; 64 windows; the table (8 entries) and the two inversions ~ 60 k slots.
-    ceiling_frac = credited mad32 / those slots: the fraction this formulation could reach if the
-    SIMDs issued one of its instructions in every mad slot."""
-    M, S, L = 417, 327, 36
+    """Floor of THIS formulation per scalar multiplication, in v_mad_u64_u32 issue slots: what the
+    kernel would take if every Fp6 operation ran at its instruction floor, nothing else were executed and the SIMDs
+    never waited.  Instruction classes are priced by their measured issue time relative to the mad
+    (profiles/r01_valu_mix_w4.json: a mad alone 2.11 ns per wave-instruction; alternating with carry-class
+    instructions, as everywhere in this arithmetic, the pair takes 3.70 ns, i.e. the carry-class instruction 1.59 ns).
+      Fp6 mul    = 36 products x (4 mad + 4 carry counts) + 6 reductions x (1 mad + 13) + 5 scalings by 7 x 9
+                 = 150 mad + 267 carry-class  -> 351 mad slots   (credited: 96)
+      Fp6 square = 21 x (4 + 4) + 6 x (1 + 13) + 5 x 9 + 5 doublings x 6 = 90 mad + 237 carry-class -> 269 (credited: 84)
+      Fp6 add / sub / double = 36 carry-class -> 27
+    Per window: 4 doublings (4 M + 4 S, the last without its z4 product; 8 linear operations each) + 1 mixed addition
+    (8 M + 5 S, 8 linear operations, the constant-time scan's 192 selects); 64 windows; the 8-entry table, the two
+    Fp6 inversions and the final normalisation ~ 55 k slots.  ceiling_frac = credited mad32 / those slots."""
+    half = (3.70 - 2.11) / 2.11
+    M = 150 + 267 * half
+    S = 90 + 237 * half
+    L = 36 * half
     dbl = 4 * M + 4 * S + 8 * L
-    scan = 8 * 24                                  # constant-time lookup: one select per 32-bit word of 8 entries
-    add = 8 * M + 5 * S + 8 * L + scan
+    add = 8 * M + 5 * S + 8 * L + 192 * half
     window = 4 * dbl - M + add
-    table_and_inversions = 60000
-    slots = 64 * window + table_and_inversions
-    return {"min_issue_slots_per_unit": slots, "ceiling_frac": MAD32_PER_CT_MULT / slots}
+    slots = 64 * window + 55000
+    return {"min_mad_slots_per_unit": round(slots), "ceiling_frac": MAD32_PER_CT_MULT / slots}
 
 
 def parse():
@@ -418,12 +422,12 @@ def main():
                          "unit": "Tmad32/s", "frac": achieved / mad_peak, "traffic": traffic,
                          "ms_per_launch": ms_launch, "units_per_launch": units_per_launch, "launches_per_pass": n_launches,
                          "mad32_per_unit": MAD32_PER_CT_MULT,
-                         "ceiling_frac": ceil["ceiling_frac"], "min_issue_slots_per_unit": ceil["min_issue_slots_per_unit"],
+                         "ceiling_frac": ceil["ceiling_frac"], "min_mad_slots_per_unit": ceil["min_mad_slots_per_unit"],
                          "frac_if_credited_as_ProjectivePoint_multiply": achieved * MAD32_PER_CT_MULT_PROJECTIVE / MAD32_PER_CT_MULT / mad_peak,
                          "note": "achieved = reference-algorithm mad32 count of AffinePoint::multiply (72588 Fp mul x 4) x units / "
                                  "HIP-event launch time; peak = v_mad_u64_u32 issue rate measured live on this device; the kernel "
                                  "is VALU-issue bound (profiles/, DESIGN.md 5): carries and reductions issue at the same rate as the mads; "
-                                 "ceiling_frac = credited mad32 / minimal issue slots of this formulation (bench.py ceiling_model, DESIGN.md 5); "
+                                 "ceiling_frac = credited mad32 / the formulation's floor in mad issue slots (bench.py ceiling_model, DESIGN.md 5); "
                                  "ms_per_launch / units_per_launch are per k_multiply_ct kernel launch (the library bounds each launch); "
                                  "traffic = (FETCH_SIZE + WRITE_SIZE) per unit from the rocprofv3 PMC passes in profiles/ x units_per_launch: "
                                  "the lane's window table is re-read in each of the 64 windows (algorithmic bytes: 225 per unit)"},
