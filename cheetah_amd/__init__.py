@@ -7,7 +7,7 @@ from ._capi import AFFINE, JACOBIAN, PROJECTIVE, CheetahError  # noqa: F401
 
 
 def __getattr__(name):  # lazy: importing the package must not need a GPU
-    if name in ("Engine", "Fp6", "AffinePoint", "ProjectivePoint", "JacobianPoint", "BASEPOINT_TABLE", "BASEPOINT_LOOKUP", "default_engine"):
+    if name in ("Engine", "Fp6", "AffinePoint", "ProjectivePoint", "JacobianPoint", "BASEPOINT_TABLE", "BASEPOINT_LOOKUP", "BasePointTable", "default_engine"):
         from . import engine
         return getattr(engine, name)
     raise AttributeError(name)

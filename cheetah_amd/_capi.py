@@ -18,7 +18,16 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_SCALAR, ERR_NOMEM = -1, -2, -3, -4, -5
 # every symbol include/cheetah_hip.h declares: (restype, argtypes)
 _vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
 SIGNATURES = {
-    "cheetah_ctx_create": (C.c_int32, [_i, C.POINTER(_vp)]),
+    "cheetah_ctx_create": (C.c_int32, [C.POINTER(C.c_int), _i, C.POINTER(_vp)]),
+    "cheetah_ctx_num_devices": (C.c_int32, [_vp]),
+    "cheetah_debug_ctx_create_replicated": (C.c_int32, [_i, _i, C.POINTER(_vp)]),
+    "cheetah_basepoint_table_create": (C.c_int32, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "cheetah_basepoint_table_destroy": (C.c_int32, [_vp]),
+    "cheetah_basepoint_table_multiply_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_basepoint_table_multiply_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "cheetah_basepoint_table_read": (C.c_int32, [_vp, _vp, _vp, _sz]),
+    "cheetah_is_on_curve_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_is_on_curve_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_ctx_destroy": (C.c_int32, [_vp]),
     "cheetah_ctx_set_stream": (C.c_int32, [_vp, _vp]),
     "cheetah_ctx_use_own_stream": (C.c_int32, [_vp]),

@@ -1,15 +1,26 @@
 // C ABI of the batched Cheetah engine (include/cheetah_hip.h).  Host side only:
-// argument checks, device buffers, kernel launches.  No CPU fallback exists: a
+// argument checks, device buffers, copies, kernel launches.  No CPU fallback exists: a
 // call either runs the HIP kernels or returns an error code.
+//
+// Every batch operation is described once (Op: its arrays, bytes per unit, and a launcher
+// that enqueues the kernels for `cnt` units on one device context) and is reached three ways:
+//   * `_dev` entry point, single-device context : the launcher, on the caller's device pointers
+//   * `_dev` entry point, multi-device context  : run_dev_multi -- contiguous shards, peer copies
+//   * host-pointer entry point                  : run_host -- per device a chunked pipeline
+//     (upload chunk k + 1 / compute chunk k / download chunk k - 1 on three streams, staging
+//     buffers kept in the context), one host thread per device when there are several
 #include "../../include/cheetah_hip.h"
 
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "kernels.hip.h"
 
@@ -25,18 +36,34 @@ constexpr int NOALLOC_MAX_BLOCKS = 128;
 constexpr size_t NOALLOC_WORDS = (size_t)NOALLOC_MAX_BLOCKS * LaneScratch::WORDS_PER_BLOCK;
 static __device__ __align__(256) u64 noalloc_scratch[NOALLOC_WORDS];
 
+namespace {
+struct DevSlot {  // grow-only device buffer owned by a context
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+}  // namespace
+
 struct cheetah_ctx {
     int device = -1;
+    int shard_index = 0;  // 0 = the context the caller holds; i > 0 = its i-th further device
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     DeviceTables* tables = nullptr;
-    u8* fixed_scalars = nullptr;  // q | cofactor, 64 bytes (is_torsion_free / clear_cofactor)
+    u8* fixed_scalars = nullptr;  // q | cofactor (64 bytes), then generator | shift point (24 words)
     u64* scratch = nullptr;
     size_t scratch_words = 0;
     u64* noalloc_arena = nullptr;  // this device's address of noalloc_scratch (hipGetSymbolAddress, once, at creation)
     int num_cus = 0;
     int reserved_cus = 0;  // CUs' worth of workgroup slots the persistent launches leave free (cheetah_ctx_set_reserved_cus)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
+    // host-pointer pipeline: copy streams, per-buffer-set events, staging buffers (two sets)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    std::vector<DevSlot> stage[2];
+    // multi-device: the caller's context is shard 0 and owns one sub-context per further device
+    std::vector<cheetah_ctx*> subs;
+    std::vector<DevSlot> peer;  // a sub-context's staging for `_dev` calls (its shard of the caller's device arrays)
+    hipEvent_t ev_peer = nullptr;
     std::string err;
 };
 
@@ -57,6 +84,7 @@ static int32_t fail(cheetah_ctx* ctx, int32_t code, const char* msg) {
     return code;
 }
 
+static bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -75,8 +103,12 @@ static const u8 FQ_MODULUS_BYTES[32] = {207, 172, 212, 174, 62, 98, 67, 212, 34,
                                         181, 55, 10, 153, 15, 191, 63, 86, 208, 34, 63, 59, 155, 89, 242, 122};
 static const u8 COFACTOR_BYTES[32] = {74, 78, 48, 84, 93, 63, 188, 73, 0, 97, 239, 113, 224, 72, 11, 21, 2};
 
+static u64* tab_field(const cheetah_ctx* c, size_t offset) {
+    return reinterpret_cast<u64*>(reinterpret_cast<char*>(c->tables) + offset);
+}
+#define TAB(c, field) tab_field(c, offsetof(DeviceTables, field))
 
-extern "C" const char* cheetah_version(void) { return "cheetah-hip 0.1 (gfx950)"; }
+extern "C" const char* cheetah_version(void) { return "cheetah-hip 0.2 (gfx950)"; }
 
 extern "C" const char* cheetah_last_error(const cheetah_ctx* ctx) {
     if (ctx) return ctx->err.c_str();
@@ -84,25 +116,47 @@ extern "C" const char* cheetah_last_error(const cheetah_ctx* ctx) {
     return g_create_err.c_str();
 }
 
+// ------------------------------------------------------------------ context -----
+
+static void destroy_one(cheetah_ctx* ctx) {
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->s_in) (void)hipStreamSynchronize(ctx->s_in);
+    if (ctx->s_out) (void)hipStreamSynchronize(ctx->s_out);
+    if (ctx->tables) (void)hipFree(ctx->tables);
+    if (ctx->fixed_scalars) (void)hipFree(ctx->fixed_scalars);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (int s = 0; s < 2; s++)
+        for (auto& d : ctx->stage[s])
+            if (d.p) (void)hipFree(d.p);
+    for (auto& d : ctx->peer)
+        if (d.p) (void)hipFree(d.p);
+    hipEvent_t evs[] = {ctx->ev0, ctx->ev1, ctx->ev_order, ctx->ev_peer, ctx->ev_in[0], ctx->ev_in[1],
+                        ctx->ev_k[0], ctx->ev_k[1], ctx->ev_out[0], ctx->ev_out[1]};
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+    if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
 static int32_t create_fail(cheetah_ctx* ctx, int32_t code, const std::string& msg) {
     {
         std::lock_guard<std::mutex> lk(g_err_mu);
         g_create_err = msg;
     }
-    if (ctx) cheetah_ctx_destroy(ctx);
+    if (ctx) destroy_one(ctx);
     return code;
 }
 
-extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
-    if (!out) return create_fail(nullptr, CHEETAH_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return create_fail(nullptr, CHEETAH_ERR_NO_DEVICE, "no HIP device visible");
-    if (device_id < 0 || device_id >= ndev) return create_fail(nullptr, CHEETAH_ERR_INVALID, "device_id out of range");
+// One device: streams, events, the reference's lazy_static tables built on the device, the ladder kernels'
+// window-table arena for the largest resident grid (so that no later `_dev` call has to allocate or synchronise).
+static int32_t create_one(int device_id, int shard_index, cheetah_ctx** out) {
     cheetah_ctx* ctx = new (std::nothrow) cheetah_ctx();
     if (!ctx) return create_fail(nullptr, CHEETAH_ERR_NOMEM, "out of host memory");
     ctx->device = device_id;
+    ctx->shard_index = shard_index;
 #define CREATE_TRY(expr)                                                                             \
     do {                                                                                             \
         hipError_t e__ = (expr);                                                                     \
@@ -116,43 +170,97 @@ extern "C" int32_t cheetah_ctx_create(int device_id, cheetah_ctx** out) {
         return create_fail(ctx, CHEETAH_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     ctx->num_cus = prop.multiProcessorCount;
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     CREATE_TRY(hipEventCreate(&ctx->ev0));
     CREATE_TRY(hipEventCreate(&ctx->ev1));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_peer, hipEventDisableTiming));
+    for (int s = 0; s < 2; s++) {
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_in[s], hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_k[s], hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_out[s], hipEventDisableTiming));
+    }
     CREATE_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ctx->noalloc_arena), HIP_SYMBOL(noalloc_scratch)));
     CREATE_TRY(hipMalloc(&ctx->tables, sizeof(DeviceTables)));
-    CREATE_TRY(hipMalloc(&ctx->fixed_scalars, 64));
+    CREATE_TRY(hipMalloc(&ctx->fixed_scalars, 64 + 24 * sizeof(u64)));
+    u64* seeds = reinterpret_cast<u64*>(ctx->fixed_scalars + 64);  // generator | shift point, read by the table kernels
     CREATE_TRY(hipMemcpyAsync(ctx->fixed_scalars, FQ_MODULUS_BYTES, 32, hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyAsync(ctx->fixed_scalars + 32, COFACTOR_BYTES, 32, hipMemcpyHostToDevice, ctx->stream));
-    u64* seeds = nullptr;
-    CREATE_TRY(hipMalloc(&seeds, 24 * sizeof(u64)));
     CREATE_TRY(hipMemcpyAsync(seeds, GENERATOR_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyAsync(seeds + 12, SHIFT_XY, 12 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(BUILD_TABLES_THREADS), 0, ctx->stream, ctx->tables, seeds, seeds + 12);
-    hipLaunchKernelGGL(k_build_wide_table, dim3(WIDE_WINDOWS), dim3(64), 0, ctx->stream, ctx->tables, seeds);
+    hipLaunchKernelGGL((k_build_comb_table<0>), dim3(1), dim3(64), 0, ctx->stream, TAB(ctx, basepoint), seeds);
+    hipLaunchKernelGGL((k_build_wide_table<0>), dim3(WIDE_WINDOWS), dim3(64), 0, ctx->stream, TAB(ctx, wide), seeds);
     CREATE_TRY(hipGetLastError());
+    const int waves = CH_CT_WAVES > CH_VT_WAVES ? CH_CT_WAVES : CH_VT_WAVES;
+    ctx->scratch_words = (size_t)ctx->num_cus * waves * LaneScratch::WORDS_PER_BLOCK;
+    CREATE_TRY(hipMalloc(&ctx->scratch, ctx->scratch_words * sizeof(u64)));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
-    CREATE_TRY(hipFree(seeds));
 #undef CREATE_TRY
     *out = ctx;
     return CHEETAH_OK;
 }
 
-extern "C" int32_t cheetah_ctx_destroy(cheetah_ctx* ctx) {
-    if (!ctx) return CHEETAH_ERR_INVALID;
-    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    if (ctx->tables) (void)hipFree(ctx->tables);
-    if (ctx->fixed_scalars) (void)hipFree(ctx->fixed_scalars);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    delete ctx;
+static int32_t create_multi(const int* device_ids, int n_dev, bool allow_duplicates, cheetah_ctx** out) {
+    if (!out) return create_fail(nullptr, CHEETAH_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_dev < 1 || n_dev > 64) return create_fail(nullptr, CHEETAH_ERR_INVALID, "device_ids is NULL or n_dev is not in [1, 64]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return create_fail(nullptr, CHEETAH_ERR_NO_DEVICE, "no HIP device visible");
+    for (int i = 0; i < n_dev; i++) {
+        if (device_ids[i] < 0 || device_ids[i] >= ndev)
+            return create_fail(nullptr, CHEETAH_ERR_INVALID, "device id " + std::to_string(device_ids[i]) + " out of range (" + std::to_string(ndev) + " visible)");
+        for (int j = 0; j < i && !allow_duplicates; j++)
+            if (device_ids[j] == device_ids[i])
+                return create_fail(nullptr, CHEETAH_ERR_INVALID, "device id " + std::to_string(device_ids[i]) + " listed twice");
+    }
+    cheetah_ctx* front = nullptr;
+    if (int32_t rc = create_one(device_ids[0], 0, &front)) return rc;
+    for (int i = 1; i < n_dev; i++) {
+        cheetah_ctx* sub = nullptr;
+        if (int32_t rc = create_one(device_ids[i], i, &sub)) {
+            for (cheetah_ctx* s : front->subs) destroy_one(s);
+            destroy_one(front);
+            return rc;
+        }
+        front->subs.push_back(sub);
+        if (device_ids[i] != device_ids[0]) {  // direct xGMI copies between the shards' devices where the platform allows
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) {
+                (void)hipSetDevice(device_ids[i]);
+                (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+                (void)hipSetDevice(device_ids[0]);
+                (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+                (void)hipGetLastError();  // "already enabled" is not an error here
+            }
+        }
+    }
+    (void)hipSetDevice(device_ids[0]);
+    *out = front;
     return CHEETAH_OK;
 }
+
+extern "C" int32_t cheetah_ctx_create(const int* device_ids, int n_dev, cheetah_ctx** out) {
+    return create_multi(device_ids, n_dev, false, out);
+}
+
+extern "C" int32_t cheetah_debug_ctx_create_replicated(int device_id, int n_shards, cheetah_ctx** out) {
+    if (n_shards < 1 || n_shards > 64) return create_fail(nullptr, CHEETAH_ERR_INVALID, "n_shards is not in [1, 64]");
+    std::vector<int> ids((size_t)n_shards, device_id);
+    return create_multi(ids.data(), n_shards, true, out);
+}
+
+extern "C" int32_t cheetah_ctx_destroy(cheetah_ctx* ctx) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    for (cheetah_ctx* s : ctx->subs) destroy_one(s);
+    destroy_one(ctx);
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_ctx_num_devices(const cheetah_ctx* ctx) { return ctx ? 1 + (int32_t)ctx->subs.size() : CHEETAH_ERR_INVALID; }
 
 // The context's kernels share its scratch arena, so its work must stay ordered when the
 // stream changes: the new stream waits (on the device, no host sync) for what the
@@ -178,8 +286,20 @@ extern "C" int32_t cheetah_ctx_use_own_stream(cheetah_ctx* ctx) {
 
 extern "C" int32_t cheetah_ctx_synchronize(cheetah_ctx* ctx) {
     if (!ctx) return CHEETAH_ERR_INVALID;
+    for (cheetah_ctx* s : ctx->subs) {
+        HIP_TRY(ctx, hipSetDevice(s->device));
+        HIP_TRY(ctx, hipStreamSynchronize(s->stream));
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx* ctx, int cus) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (cus < 0 || cus >= ctx->num_cus) return fail(ctx, CHEETAH_ERR_INVALID, "reserved CUs must be in [0, number of CUs)");
+    ctx->reserved_cus = cus;
+    for (cheetah_ctx* s : ctx->subs) s->reserved_cus = cus;
     return CHEETAH_OK;
 }
 
@@ -195,9 +315,11 @@ static int lane_grid(const cheetah_ctx* ctx, size_t n_lanes_needed, int blocks_p
 
 constexpr int ROUNDS_PER_LAUNCH = 2;
 
+// The arena is sized at creation for the single-scalar ladders; only the multi-scalar kernels with many points per
+// group need more, and then only the first time: the context's stream is drained before the old arena is released.
 static int32_t ensure_scratch(cheetah_ctx* ctx, size_t words) {
     if (ctx->scratch_words >= words) return CHEETAH_OK;
-    HIP_TRY(ctx, hipDeviceSynchronize());  // nothing may still be using the old arena
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) HIP_TRY(ctx, hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_words = 0;
@@ -206,19 +328,239 @@ static int32_t ensure_scratch(cheetah_ctx* ctx, size_t words) {
     return CHEETAH_OK;
 }
 
-#define CHECK_CTX(ctx)                                   \
-    do {                                                 \
-        if (!(ctx)) return CHEETAH_ERR_INVALID;          \
-        HIP_TRY(ctx, hipSetDevice((ctx)->device));       \
-    } while (0)
+static int32_t ensure_slot(cheetah_ctx* c, DevSlot& d, size_t bytes, hipStream_t user) {
+    if (d.bytes >= bytes) return CHEETAH_OK;
+    if (d.p) {
+        HIP_TRY(c, hipStreamSynchronize(user));
+        HIP_TRY(c, hipFree(d.p));
+        d.p = nullptr;
+        d.bytes = 0;
+    }
+    HIP_TRY(c, hipMalloc(&d.p, bytes));
+    d.bytes = bytes;
+    return CHEETAH_OK;
+}
+
+#define SET_DEVICE(ctx) HIP_TRY(ctx, hipSetDevice((ctx)->device))
+
+// ------------------------------------------------------- generic dispatch -----
+
+namespace {
+struct Io {
+    const void* in = nullptr;  // input array, or
+    void* out = nullptr;       // output array
+    size_t stride = 0;         // bytes per unit
+    bool is_out = false;
+    bool optional = false;     // output the caller may pass as NULL
+    bool dev_always = false;   // host-pointer path: the kernels need a device array even when the caller's is NULL
+};
+Io in_(const void* p, size_t stride) {
+    Io io;
+    io.in = p;
+    io.stride = stride;
+    return io;
+}
+Io out_(void* p, size_t stride, bool optional = false, bool dev_always = false) {
+    Io io;
+    io.out = p;
+    io.stride = stride;
+    io.is_out = true;
+    io.optional = optional;
+    io.dev_always = dev_always;
+    return io;
+}
+using LaunchFn = std::function<int32_t(cheetah_ctx*, void* const*, size_t)>;
+struct Op {
+    size_t n = 0;
+    std::vector<Io> io;
+    size_t chunk = (size_t)1 << 20;  // units per pipeline chunk of the host-pointer path (a multiple of 256)
+    LaunchFn launch;                 // enqueue the kernels for `cnt` units on context c's stream; d[j] = device array j
+};
+constexpr size_t SHARD_ALIGN = 256;  // shard boundaries: every array stays 16-byte aligned at them
+}  // namespace
+
+static void shard_range(size_t n, size_t nsh, size_t i, size_t* off, size_t* cnt) {
+    size_t per = (n + nsh - 1) / nsh;
+    per = (per + SHARD_ALIGN - 1) / SHARD_ALIGN * SHARD_ALIGN;
+    *off = i * per < n ? i * per : n;
+    *cnt = n - *off < per ? n - *off : per;
+}
+
+// Host-pointer path on ONE device: units [off, off + cnt) of the caller's host arrays.
+// Host order per chunk: upload k + 1, launch k + 1, download k -- so that while the host is
+// held by a (pageable) download, the next chunk's kernels are already queued behind the
+// running ones.  Two staging sets; events order reuse of a set on the device.
+static int32_t host_pipeline(cheetah_ctx* c, const Op& op, size_t off, size_t cnt) {
+    SET_DEVICE(c);
+    if (cnt == 0) return CHEETAH_OK;
+    const size_t chunk = op.chunk < cnt ? op.chunk : cnt;
+    const size_t nch = (cnt + chunk - 1) / chunk;
+    const int sets = nch > 1 ? 2 : 1;
+    const size_t nio = op.io.size();
+    auto used = [&](const Io& io) { return !io.is_out || io.out || io.dev_always; };
+    for (int s = 0; s < sets; s++) {
+        if (c->stage[s].size() < nio) c->stage[s].resize(nio);
+        for (size_t j = 0; j < nio; j++)
+            if (used(op.io[j]))
+                if (int32_t rc = ensure_slot(c, c->stage[s][j], chunk * op.io[j].stride, c->stream)) return rc;
+    }
+    std::vector<void*> d(nio);
+    auto span = [&](size_t k, size_t* e0, size_t* m) {
+        *e0 = off + k * chunk;
+        *m = cnt - k * chunk < chunk ? cnt - k * chunk : chunk;
+    };
+    auto upload = [&](size_t k) -> int32_t {
+        const int s = (int)(k & 1);
+        size_t e0, m;
+        span(k, &e0, &m);
+        if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->s_in, c->ev_out[s], 0));  // the set's previous results have left
+        for (size_t j = 0; j < nio; j++)
+            if (!op.io[j].is_out)
+                HIP_TRY(c, hipMemcpyAsync(c->stage[s][j].p, static_cast<const char*>(op.io[j].in) + e0 * op.io[j].stride,
+                                          m * op.io[j].stride, hipMemcpyHostToDevice, c->s_in));
+        HIP_TRY(c, hipEventRecord(c->ev_in[s], c->s_in));
+        return CHEETAH_OK;
+    };
+    auto compute = [&](size_t k) -> int32_t {
+        const int s = (int)(k & 1);
+        size_t e0, m;
+        span(k, &e0, &m);
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in[s], 0));
+        if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_out[s], 0));
+        for (size_t j = 0; j < nio; j++) d[j] = used(op.io[j]) ? c->stage[s][j].p : nullptr;
+        if (int32_t rc = op.launch(c, d.data(), m)) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_k[s], c->stream));
+        return CHEETAH_OK;
+    };
+    auto download = [&](size_t k) -> int32_t {
+        const int s = (int)(k & 1);
+        size_t e0, m;
+        span(k, &e0, &m);
+        HIP_TRY(c, hipStreamWaitEvent(c->s_out, c->ev_k[s], 0));
+        for (size_t j = 0; j < nio; j++)
+            if (op.io[j].is_out && op.io[j].out)
+                HIP_TRY(c, hipMemcpyAsync(static_cast<char*>(op.io[j].out) + e0 * op.io[j].stride, c->stage[s][j].p,
+                                          m * op.io[j].stride, hipMemcpyDeviceToHost, c->s_out));
+        HIP_TRY(c, hipEventRecord(c->ev_out[s], c->s_out));
+        return CHEETAH_OK;
+    };
+    int32_t rc = upload(0);
+    if (!rc) rc = compute(0);
+    for (size_t k = 0; k < nch && !rc; k++) {
+        if (k + 1 < nch) {
+            rc = upload(k + 1);
+            if (!rc) rc = compute(k + 1);
+        }
+        if (!rc) rc = download(k);
+    }
+    // never leave with copies in flight that touch the caller's memory, error or not
+    hipError_t e1 = hipStreamSynchronize(c->s_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->s_out);
+    if (rc) return rc;
+    HIP_TRY(c, e1);
+    HIP_TRY(c, e2);
+    HIP_TRY(c, e3);
+    return CHEETAH_OK;
+}
+
+static int32_t run_host(cheetah_ctx* ctx, const Op& op) {
+    const size_t nsh = 1 + ctx->subs.size();
+    if (nsh == 1) return host_pipeline(ctx, op, 0, op.n);
+    std::vector<int32_t> rcs(nsh, CHEETAH_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < nsh; i++) {
+        cheetah_ctx* c = i == 0 ? ctx : ctx->subs[i - 1];
+        size_t off, cnt;
+        shard_range(op.n, nsh, i, &off, &cnt);
+        th.emplace_back([&rcs, &op, c, off, cnt, i]() { rcs[i] = host_pipeline(c, op, off, cnt); });
+    }
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(ctx->device);
+    for (size_t i = 0; i < nsh; i++)
+        if (rcs[i]) {
+            if (i > 0) ctx->err = "device " + std::to_string(ctx->subs[i - 1]->device) + ": " + ctx->subs[i - 1]->err;
+            return rcs[i];
+        }
+    return CHEETAH_OK;
+}
+
+// `_dev` entry point of a multi-device context: the arrays live on the first device.  Shard 0 runs in place;
+// every further shard copies its slice to its own device (peer copy over xGMI), runs there, and copies its
+// results back into the caller's arrays.  Asynchronous: the caller's stream waits for every shard on the device.
+static int32_t run_dev_multi(cheetah_ctx* ctx, const Op& op) {
+    const size_t nsh = 1 + ctx->subs.size(), nio = op.io.size();
+    SET_DEVICE(ctx);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_order, ctx->stream));  // the inputs are ready once the caller's stream gets here
+    std::vector<void*> d(nio);
+    for (size_t i = 1; i < nsh; i++) {
+        cheetah_ctx* s = ctx->subs[i - 1];
+        size_t off, cnt;
+        shard_range(op.n, nsh, i, &off, &cnt);
+        if (cnt == 0) continue;
+        auto bail = [&](int32_t rc) {
+            ctx->err = "device " + std::to_string(s->device) + ": " + s->err;
+            (void)hipSetDevice(ctx->device);
+            return rc;
+        };
+        if (hipSetDevice(s->device) != hipSuccess) return fail(ctx, CHEETAH_ERR_HIP, "hipSetDevice failed");
+        if (s->peer.size() < nio) s->peer.resize(nio);
+        for (size_t j = 0; j < nio; j++) {
+            const Io& io = op.io[j];
+            const bool used = !io.is_out || io.out;
+            d[j] = nullptr;
+            if (!used) continue;
+            if (int32_t rc = ensure_slot(s, s->peer[j], cnt * io.stride, s->stream)) return bail(rc);
+            d[j] = s->peer[j].p;
+        }
+        if (hipStreamWaitEvent(s->stream, ctx->ev_order, 0) != hipSuccess) return fail(ctx, CHEETAH_ERR_HIP, "hipStreamWaitEvent failed");
+        for (size_t j = 0; j < nio; j++)
+            if (!op.io[j].is_out)
+                if (hipMemcpyPeerAsync(d[j], s->device, static_cast<const char*>(op.io[j].in) + off * op.io[j].stride, ctx->device,
+                                       cnt * op.io[j].stride, s->stream) != hipSuccess)
+                    return fail(ctx, CHEETAH_ERR_HIP, "hipMemcpyPeerAsync (inputs) failed");
+        if (int32_t rc = op.launch(s, d.data(), cnt)) return bail(rc);
+        for (size_t j = 0; j < nio; j++)
+            if (op.io[j].is_out && op.io[j].out)
+                if (hipMemcpyPeerAsync(static_cast<char*>(op.io[j].out) + off * op.io[j].stride, ctx->device, d[j], s->device,
+                                       cnt * op.io[j].stride, s->stream) != hipSuccess)
+                    return fail(ctx, CHEETAH_ERR_HIP, "hipMemcpyPeerAsync (results) failed");
+        if (hipEventRecord(s->ev_peer, s->stream) != hipSuccess) return fail(ctx, CHEETAH_ERR_HIP, "hipEventRecord failed");
+    }
+    SET_DEVICE(ctx);
+    size_t off0, cnt0;
+    shard_range(op.n, nsh, 0, &off0, &cnt0);
+    for (size_t j = 0; j < nio; j++) d[j] = op.io[j].is_out ? op.io[j].out : const_cast<void*>(op.io[j].in);
+    if (cnt0)
+        if (int32_t rc = op.launch(ctx, d.data(), cnt0)) return rc;
+    for (size_t i = 1; i < nsh; i++) {
+        size_t off, cnt;
+        shard_range(op.n, nsh, i, &off, &cnt);
+        if (cnt) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->subs[i - 1]->ev_peer, 0));
+    }
+    return CHEETAH_OK;
+}
+
+static int32_t run_op(cheetah_ctx* ctx, bool host, const Op& op) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (op.n == 0) return CHEETAH_OK;
+    for (const Io& io : op.io)
+        if ((!io.is_out && !io.in) || (io.is_out && !io.out && !io.optional)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    if (host) return run_host(ctx, op);
+    if (!ctx->subs.empty()) return run_dev_multi(ctx, op);
+    std::vector<void*> d(op.io.size());
+    for (size_t j = 0; j < op.io.size(); j++) d[j] = op.io[j].is_out ? op.io[j].out : const_cast<void*>(op.io[j].in);
+    return op.launch(ctx, d.data(), op.n);
+}
+
+template <class T>
+static T* at(void* const* d, int j) {
+    return static_cast<T*>(d[j]);
+}
 
 // ---------------------------------------------------------------- Fp6 -----
 
 template <int OP>
-static int32_t fp6_elementwise_dev(cheetah_ctx* ctx, const u64* a, const u64* b, u64* out, u8* is_some, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!a || !out || (OP == EW_MUL && !b)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+static int32_t fp6_elementwise_impl(cheetah_ctx* ctx, const u64* a, const u64* b, u64* out, u8* is_some, size_t n) {
+    SET_DEVICE(ctx);
     if (!aligned16(a) || !aligned16(out) || (b && !aligned16(b))) return fail(ctx, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
     size_t tiles = (n + BLOCK - 1) / BLOCK;
     // Measured (tools/fp6_ew_bench.py): batches beyond the Infinity Cache stream fastest with one element per
@@ -231,26 +573,57 @@ static int32_t fp6_elementwise_dev(cheetah_ctx* ctx, const u64* a, const u64* b,
     return CHEETAH_OK;
 }
 
+static int32_t fp6_mul_op(cheetah_ctx* ctx, bool host, const u64* a, const u64* b, u64* out, size_t n) {
+    Op op;
+    op.n = n;
+    op.io = {in_(a, 48), in_(b, 48), out_(out, 48)};
+    op.launch = [](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return fp6_elementwise_impl<EW_MUL>(c, at<u64>(d, 0), at<u64>(d, 1), at<u64>(d, 2), nullptr, cnt);
+    };
+    return run_op(ctx, host, op);
+}
+template <int OP>
+static int32_t fp6_unary_op(cheetah_ctx* ctx, bool host, const u64* a, u64* out, u8* is_some, size_t n) {
+    Op op;
+    op.n = n;
+    op.io = {in_(a, 48), out_(out, 48)};
+    if (OP != EW_SQUARE) op.io.push_back(out_(is_some, 1));
+    op.launch = [](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return fp6_elementwise_impl<OP>(c, at<u64>(d, 0), nullptr, at<u64>(d, 1), OP != EW_SQUARE ? at<u8>(d, 2) : nullptr, cnt);
+    };
+    return run_op(ctx, host, op);
+}
+
 extern "C" int32_t cheetah_fp6_mul_batch_dev(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    return fp6_elementwise_dev<EW_MUL>(ctx, a, b, out, nullptr, n);
+    return fp6_mul_op(ctx, false, a, b, out, n);
+}
+extern "C" int32_t cheetah_fp6_mul_batch(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return fp6_mul_op(ctx, true, a, b, out, n);
 }
 extern "C" int32_t cheetah_fp6_square_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
-    return fp6_elementwise_dev<EW_SQUARE>(ctx, a, nullptr, out, nullptr, n);
+    return fp6_unary_op<EW_SQUARE>(ctx, false, a, out, nullptr, n);
+}
+extern "C" int32_t cheetah_fp6_square_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return fp6_unary_op<EW_SQUARE>(ctx, true, a, out, nullptr, n);
 }
 extern "C" int32_t cheetah_fp6_invert_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
-    return fp6_elementwise_dev<EW_INVERT>(ctx, a, nullptr, out, is_some, n);
+    return fp6_unary_op<EW_INVERT>(ctx, false, a, out, is_some, n);
+}
+extern "C" int32_t cheetah_fp6_invert_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    return fp6_unary_op<EW_INVERT>(ctx, true, a, out, is_some, n);
 }
 extern "C" int32_t cheetah_fp6_sqrt_batch_dev(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
-    return fp6_elementwise_dev<EW_SQRT>(ctx, a, nullptr, out, is_some, n);
+    return fp6_unary_op<EW_SQRT>(ctx, false, a, out, is_some, n);
+}
+extern "C" int32_t cheetah_fp6_sqrt_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
+    return fp6_unary_op<EW_SQRT>(ctx, true, a, out, is_some, n);
 }
 
 // ------------------------------------------------------ batch_normalize -----
 
 template <int JAC>
-static int32_t batch_normalize_dev(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8* inf, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!xyz || !xy || !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+static int32_t batch_normalize_impl(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8* inf, size_t n) {
+    SET_DEVICE(ctx);
     if (!aligned16(xyz) || !aligned16(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "point arrays must be 16-byte aligned");
     constexpr int CHUNK = 8;
     size_t nchunks = (n + CHUNK - 1) / CHUNK;
@@ -259,20 +632,35 @@ static int32_t batch_normalize_dev(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }
+template <int JAC>
+static int32_t batch_normalize_op(cheetah_ctx* ctx, bool host, const u64* xyz, u64* xy, u8* inf, size_t n) {
+    Op op;
+    op.n = n;
+    op.io = {in_(xyz, 144), out_(xy, 96), out_(inf, 1)};
+    op.launch = [](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return batch_normalize_impl<JAC>(c, at<u64>(d, 0), at<u64>(d, 1), at<u8>(d, 2), cnt);
+    };
+    return run_op(ctx, host, op);
+}
 extern "C" int32_t cheetah_batch_normalize_projective_dev(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
-    return batch_normalize_dev<0>(ctx, xyz, xy, inf, n);
+    return batch_normalize_op<0>(ctx, false, xyz, xy, inf, n);
 }
 extern "C" int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
-    return batch_normalize_dev<1>(ctx, xyz, xy, inf, n);
+    return batch_normalize_op<1>(ctx, false, xyz, xy, inf, n);
+}
+extern "C" int32_t cheetah_batch_normalize_projective(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
+    return batch_normalize_op<0>(ctx, true, xyz, xy, inf, n);
+}
+extern "C" int32_t cheetah_batch_normalize_jacobian(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
+    return batch_normalize_op<1>(ctx, true, xyz, xy, inf, n);
 }
 
 // ------------------------------------------------------------- ladders -----
 
-// Which reference ladder a (in_form, out_form) pair names:
-//   PROJECTIVE on either side -> ProjectivePoint::multiply*           (projective accumulator)
-//   otherwise                 -> JacobianPoint / AffinePoint::multiply* (modified-Jacobian accumulator;
-//                                AffinePoint's methods delegate to JacobianPoint's, src/curve/affine.rs:373-386)
-// PROJECTIVE <-> JACOBIAN has no counterpart in the reference and is rejected.
+// Which reference ladder a (in_form, out_form) pair names (include/cheetah_hip.h): the point a call returns is
+// always the reference method's; with AFFINE results it does not depend on the accumulator's coordinates, and
+// the modified-Jacobian ladder (JacobianPoint's, which AffinePoint's methods delegate to) is run because it is
+// cheaper.  PROJECTIVE <-> JACOBIAN has no counterpart in the reference and is rejected.
 static int32_t check_forms(cheetah_ctx* ctx, int in_form, int out_form) {
     if (in_form < CHEETAH_AFFINE || in_form > CHEETAH_JACOBIAN) return fail(ctx, CHEETAH_ERR_INVALID, "in_form must be AFFINE, PROJECTIVE or JACOBIAN");
     if (out_form < CHEETAH_AFFINE || out_form > CHEETAH_JACOBIAN) return fail(ctx, CHEETAH_ERR_INVALID, "out_form must be AFFINE, PROJECTIVE or JACOBIAN");
@@ -280,14 +668,17 @@ static int32_t check_forms(cheetah_ctx* ctx, int in_form, int out_form) {
         return fail(ctx, CHEETAH_ERR_INVALID, "PROJECTIVE and JACOBIAN cannot be mixed in one call");
     return CHEETAH_OK;
 }
+static size_t form_limbs(int form) { return form == CHEETAH_AFFINE ? 12 : 18; }
 
-extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const uint8_t* scalars32, uint64_t* out, uint8_t* inf,
-                                                      size_t n, int out_form) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+// Fixed base.  comb / wide: the base's BasePointTable (32 x LookupTable<8>) and its widened table; GENERIC: a
+// caller-supplied base (tables may hold identities).
+template <bool GENERIC>
+static int32_t fixed_base_impl(cheetah_ctx* ctx, const u64* comb, const u64* wide, const u8* scalars32, u64* out, u8* inf, size_t n,
+                               int out_form) {
+    SET_DEVICE(ctx);
     if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    if (out_form != CHEETAH_JACOBIAN && !inf)
+        return fail(ctx, CHEETAH_ERR_INVALID, "inf must not be NULL for BasePointTable forms: it carries the out-of-range flag 0xFF");
     if (out_form == CHEETAH_AFFINE) {  // affine results: the widened comb (one 1 024-thread workgroup per CU)
         size_t want = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
         const size_t cus_w = (size_t)(ctx->num_cus - ctx->reserved_cus);
@@ -295,45 +686,180 @@ extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const ui
         const size_t per_launch_w = (size_t)grid_w * WIDE_BLOCK * ROUNDS_PER_LAUNCH * 4;
         for (size_t off = 0; off < n; off += per_launch_w) {
             const size_t cnt = n - off < per_launch_w ? n - off : per_launch_w;
-            hipLaunchKernelGGL(k_mul_by_generator_wide, dim3(grid_w), dim3(WIDE_BLOCK), 0, ctx->stream, ctx->tables,
+            hipLaunchKernelGGL((k_mul_by_generator_wide<GENERIC>), dim3(grid_w), dim3(WIDE_BLOCK), 0, ctx->stream, ctx->tables, wide,
                                scalars32 + off * 32, out + off * 12, inf + off, cnt);
         }
         HIP_TRY(ctx, hipGetLastError());
         return CHEETAH_OK;
     }
     int grid = lane_grid(ctx, n, CH_GEN_WAVES);
-    const size_t out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
-    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH * 4;  // bounded launches, as in multiply_dev
+    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH * 4;  // bounded launches, as in multiply_impl
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u8* sc_o = scalars32 + off * 32;
-        u64* out_o = out + off * out_w;
+        u64* out_o = out + off * 18;
         u8* inf_o = inf ? inf + off : nullptr;
-        if (out_form == CHEETAH_AFFINE)
-            hipLaunchKernelGGL((k_mul_by_generator<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, sc_o, out_o, inf_o, cnt);
-        else if (out_form == CHEETAH_PROJECTIVE)
-            hipLaunchKernelGGL((k_mul_by_generator<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, sc_o, out_o, inf_o, cnt);
-        else
+        if (out_form == CHEETAH_PROJECTIVE)
+            hipLaunchKernelGGL((k_mul_by_generator<1, GENERIC>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, comb, sc_o, out_o, inf_o, cnt);
+        else if (!GENERIC)
             hipLaunchKernelGGL((k_mul_by_generator_lookup<2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, sc_o, out_o, inf_o, cnt);
     }
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }
 
-// arena == nullptr: the context's own scratch (grown on demand); otherwise a caller-chosen arena that holds
+// BASEPOINT_TABLE's range check of the host-pointer entry points
+static int32_t check_comb_range(cheetah_ctx* ctx, const u8* scalars32, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        if ((scalars32[32 * i + 31] >> 4) > 7)
+            return fail(ctx, CHEETAH_ERR_SCALAR, "scalar with top nibble > 7: outside BasePointTable's LookupTable<8> range");
+    return CHEETAH_OK;
+}
+
+static int32_t mul_by_generator_op(cheetah_ctx* ctx, bool host, const u8* scalars32, u64* out, u8* inf, size_t n, int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
+    if (n == 0) return CHEETAH_OK;
+    if (host && out_form != CHEETAH_JACOBIAN && scalars32)  // BASEPOINT_LOOKUP's LookupTable<128> covers every radix-256 digit
+        if (int32_t rc = check_comb_range(ctx, scalars32, n)) return rc;
+    Op op;
+    op.n = n;
+    op.chunk = (size_t)1 << 19;
+    op.io = {in_(scalars32, 32), out_(out, form_limbs(out_form) * 8),
+             out_(inf, 1, /*optional*/ (host && out_form != CHEETAH_AFFINE) || out_form == CHEETAH_JACOBIAN,
+                  /*dev_always*/ out_form != CHEETAH_JACOBIAN)};
+    op.launch = [out_form](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return fixed_base_impl<false>(c, TAB(c, basepoint), TAB(c, wide), at<u8>(d, 0), at<u64>(d, 1), at<u8>(d, 2), cnt, out_form);
+    };
+    return run_op(ctx, host, op);
+}
+extern "C" int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx* ctx, const uint8_t* scalars32, uint64_t* out, uint8_t* inf,
+                                                      size_t n, int out_form) {
+    return mul_by_generator_op(ctx, false, scalars32, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_mul_by_generator_batch(cheetah_ctx* ctx, const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
+                                                  int out_form) {
+    return mul_by_generator_op(ctx, true, scalars32, out, inf, n, out_form);
+}
+
+// ---- BasePointTable::create(P) / multiply for a caller-supplied base (src/lookup.rs:164-206) ----
+
+struct cheetah_basepoint_table {
+    cheetah_ctx* ctx = nullptr;
+    std::vector<u64*> comb, wide;  // one copy per shard of the context
+};
+constexpr size_t COMB_WORDS = 32 * 8 * 12, WIDE_WORDS = (size_t)WIDE_WINDOWS * WIDE_ENTRIES * 12;
+
+extern "C" int32_t cheetah_basepoint_table_destroy(cheetah_basepoint_table* t) {
+    if (!t) return CHEETAH_ERR_INVALID;
+    for (size_t i = 0; i < t->comb.size(); i++) {
+        cheetah_ctx* c = i == 0 ? t->ctx : t->ctx->subs[i - 1];
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (t->comb[i]) (void)hipFree(t->comb[i]);  // comb and wide are one allocation
+    }
+    (void)hipSetDevice(t->ctx->device);
+    delete t;
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_basepoint_table_create(cheetah_ctx* ctx, const uint64_t* point, int in_form, cheetah_basepoint_table** out) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (!out || !point) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    *out = nullptr;
+    if (in_form != CHEETAH_AFFINE && in_form != CHEETAH_PROJECTIVE)
+        return fail(ctx, CHEETAH_ERR_INVALID, "BasePointTable is created from an AffinePoint or a ProjectivePoint (src/lookup.rs:138-173)");
+    cheetah_basepoint_table* t = new (std::nothrow) cheetah_basepoint_table();
+    if (!t) return fail(ctx, CHEETAH_ERR_NOMEM, "out of host memory");
+    t->ctx = ctx;
+    const size_t nsh = 1 + ctx->subs.size(), pt_words = form_limbs(in_form);
+    t->comb.assign(nsh, nullptr);
+    t->wide.assign(nsh, nullptr);
+    for (size_t i = 0; i < nsh; i++) {
+        cheetah_ctx* c = i == 0 ? ctx : ctx->subs[i - 1];
+        u64* buf = nullptr;
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipMalloc(&buf, (COMB_WORDS + WIDE_WORDS + 24) * sizeof(u64));
+        if (e == hipSuccess) {
+            t->comb[i] = buf;
+            t->wide[i] = buf + COMB_WORDS;
+            u64* pt = buf + COMB_WORDS + WIDE_WORDS;
+            e = hipMemcpyAsync(pt, point, pt_words * sizeof(u64), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                if (in_form == CHEETAH_AFFINE) {
+                    hipLaunchKernelGGL((k_build_comb_table<0>), dim3(1), dim3(64), 0, c->stream, t->comb[i], pt);
+                    hipLaunchKernelGGL((k_build_wide_table<0>), dim3(WIDE_WINDOWS), dim3(64), 0, c->stream, t->wide[i], pt);
+                } else {
+                    hipLaunchKernelGGL((k_build_comb_table<1>), dim3(1), dim3(64), 0, c->stream, t->comb[i], pt);
+                    hipLaunchKernelGGL((k_build_wide_table<1>), dim3(WIDE_WINDOWS), dim3(64), 0, c->stream, t->wide[i], pt);
+                }
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `point` is the caller's: done with it on return
+        }
+        if (e != hipSuccess) {
+            ctx->err = std::string("cheetah_basepoint_table_create: ") + hipGetErrorString(e);
+            cheetah_basepoint_table_destroy(t);
+            return CHEETAH_ERR_HIP;
+        }
+    }
+    (void)hipSetDevice(ctx->device);
+    *out = t;
+    return CHEETAH_OK;
+}
+
+static int32_t table_multiply_op(cheetah_ctx* ctx, bool host, const cheetah_basepoint_table* t, const u8* scalars32, u64* out, u8* inf,
+                                 size_t n, int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (!t || t->ctx != ctx) return fail(ctx, CHEETAH_ERR_INVALID, "the table does not belong to this context");
+    if (out_form != CHEETAH_AFFINE && out_form != CHEETAH_PROJECTIVE)
+        return fail(ctx, CHEETAH_ERR_INVALID, "BasePointTable::multiply returns a ProjectivePoint (or its affine point): out_form must be AFFINE or PROJECTIVE");
+    if (n == 0) return CHEETAH_OK;
+    if (host && scalars32)
+        if (int32_t rc = check_comb_range(ctx, scalars32, n)) return rc;
+    Op op;
+    op.n = n;
+    op.chunk = (size_t)1 << 19;
+    op.io = {in_(scalars32, 32), out_(out, form_limbs(out_form) * 8), out_(inf, 1, host && out_form != CHEETAH_AFFINE, true)};
+    op.launch = [out_form, t](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return fixed_base_impl<true>(c, t->comb[c->shard_index], t->wide[c->shard_index], at<u8>(d, 0), at<u64>(d, 1), at<u8>(d, 2), cnt,
+                                     out_form);
+    };
+    return run_op(ctx, host, op);
+}
+extern "C" int32_t cheetah_basepoint_table_multiply_batch(cheetah_ctx* ctx, const cheetah_basepoint_table* t, const uint8_t* scalars32,
+                                                          uint64_t* out, uint8_t* inf, size_t n, int out_form) {
+    return table_multiply_op(ctx, true, t, scalars32, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_basepoint_table_multiply_batch_dev(cheetah_ctx* ctx, const cheetah_basepoint_table* t,
+                                                              const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
+                                                              int out_form) {
+    return table_multiply_op(ctx, false, t, scalars32, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_basepoint_table_read(cheetah_ctx* ctx, const cheetah_basepoint_table* t, uint64_t* out_xy, size_t max_points) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (!t || t->ctx != ctx || !out_xy) return fail(ctx, CHEETAH_ERR_INVALID, "bad table or null pointer");
+    SET_DEVICE(ctx);
+    const size_t pts = max_points < 256 ? max_points : 256;
+    HIP_TRY(ctx, hipMemcpyAsync(out_xy, t->comb[0], pts * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+// ---- variable base ----
+
+// arena == nullptr: the context's own scratch; otherwise a caller-chosen arena that holds
 // max_blocks workgroups' tables, and the grids are capped to it (the kernels grid-stride over the rest).
 template <bool VARTIME>
-static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
-                            int out_form, u64* arena = nullptr, int max_blocks = 0) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
+                             int out_form, u64* arena = nullptr, int max_blocks = 0) {
+    SET_DEVICE(ctx);
+    if (out_form == CHEETAH_AFFINE && !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     // multiply_vartime with AFFINE results: the fixed-window ladder with indexed lookups (k_multiply_ct<..., DIRECT>)
     // for every wave whose scalars are all below 2^255, then the reference's NAF ladder for the remaining waves.
     const bool direct = VARTIME && out_form == CHEETAH_AFFINE;
-    // the ONLY_WIDE instance of the NAF kernel (normally nothing to do) is compiled for 2 waves: no scratch
+    // the ONLY_WIDE instance of the NAF kernel (normally nothing to do) is compiled for 2 waves
     int grid_vt = lane_grid(ctx, n, direct ? 2 : CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
     if (arena) {
         if (grid_vt > max_blocks) grid_vt = max_blocks;
@@ -343,11 +869,10 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         arena = ctx->scratch;
     }
     const int grid = (VARTIME && !direct) ? grid_vt : grid_ct;
-    // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (~25 ms of
-    // work).  The workgroups are persistent within a launch and fill every CU, so a kernel
-    // on another stream (the RCCL all-gather of the previous chunk) can only get CU slots
-    // at a launch boundary: bounding the launch bounds how long it waits.
-    const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (18 ms of work at 4 workgroups per CU).
+    // The workgroups are persistent within a launch and fill every CU, so a kernel on another stream (the RCCL
+    // all-gather of the previous chunk) can only get CU slots at a launch boundary: bounding the launch bounds its wait.
+    const size_t in_w = form_limbs(in_form), out_w = form_limbs(out_form);
     const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
@@ -355,221 +880,97 @@ static int32_t multiply_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const
         const u8* sc_o = scalars32 + off * 32;
         u64* out_o = out + off * out_w;
         u8* inf_o = inf ? inf + off : nullptr;
-#define LAUNCH(KERN, A, I, O)                                                                                                   \
+#define LAUNCH(A, I, O)                                                                                                        \
     do {                                                                                                                       \
-        if constexpr (VARTIME && O == 0) {                                                                                             \
+        if constexpr (VARTIME && O == 0) {                                                                                     \
             hipLaunchKernelGGL((k_multiply_ct<A, I, O, true>), dim3(grid_ct), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,  \
-                               sc_o, out_o, inf_o, cnt, arena);                                                         \
+                               sc_o, out_o, inf_o, cnt, arena);                                                                \
             hipLaunchKernelGGL((k_multiply_vartime<A, I, O, true>), dim3(grid_vt), dim3(BLOCK), 0, ctx->stream, ctx->tables,    \
-                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                               \
-        } else if constexpr (VARTIME)                                                                                              \
+                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                                      \
+        } else if constexpr (VARTIME)                                                                                          \
             hipLaunchKernelGGL((k_multiply_vartime<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,      \
-                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                               \
+                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                                      \
         else                                                                                                                   \
             hipLaunchKernelGGL((k_multiply_ct<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,    \
-                               sc_o, out_o, inf_o, cnt, arena);                                                         \
+                               sc_o, out_o, inf_o, cnt, arena);                                                                \
     } while (0)
-#define DISPATCH(KERN)                                         \
-    switch (in_form * 3 + out_form) {                          \
-        case 0: LAUNCH(KERN, MJac, 0, 0); break; /* A -> A */ \
-        case 1: LAUNCH(KERN, Proj, 0, 1); break; /* A -> P */ \
-        case 2: LAUNCH(KERN, MJac, 0, 2); break; /* A -> J */ \
-        case 3: LAUNCH(KERN, MJac, 1, 0); break; /* P -> A: the affine point is the same on either accumulator; MJac is cheaper */ \
-        case 4: LAUNCH(KERN, Proj, 1, 1); break; /* P -> P */ \
-        case 6: LAUNCH(KERN, MJac, 2, 0); break; /* J -> A */ \
-        default: LAUNCH(KERN, MJac, 2, 2); break; /* J -> J */ \
-    }
-        DISPATCH(_)
-    }
-#undef DISPATCH
+        switch (in_form * 3 + out_form) {
+            case 0: LAUNCH(MJac, 0, 0); break;  /* A -> A */
+            case 1: LAUNCH(Proj, 0, 1); break;  /* A -> P */
+            case 2: LAUNCH(MJac, 0, 2); break;  /* A -> J */
+            case 3: LAUNCH(MJac, 1, 0); break;  /* P -> A: the affine point is the same on either accumulator; MJac is cheaper */
+            case 4: LAUNCH(Proj, 1, 1); break;  /* P -> P */
+            case 6: LAUNCH(MJac, 2, 0); break;  /* J -> A */
+            default: LAUNCH(MJac, 2, 2); break; /* J -> J */
+        }
 #undef LAUNCH
+    }
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }
+
+template <bool VARTIME>
+static int32_t multiply_op(cheetah_ctx* ctx, bool host, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
+                           int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    Op op;
+    op.n = n;
+    op.chunk = (size_t)1 << 18;
+    op.io = {in_(pts, form_limbs(in_form) * 8), in_(scalars32, 32), out_(out, form_limbs(out_form) * 8),
+             out_(inf, 1, out_form != CHEETAH_AFFINE)};
+    op.launch = [in_form, out_form](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return multiply_impl<VARTIME>(c, at<u64>(d, 0), in_form, at<u8>(d, 1), at<u64>(d, 2), at<u8>(d, 3), cnt, out_form);
+    };
+    return run_op(ctx, host, op);
+}
 extern "C" int32_t cheetah_multiply_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
                                               uint64_t* out, uint8_t* inf, size_t n, int out_form) {
-    return multiply_dev<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+    return multiply_op<false>(ctx, false, pts, in_form, scalars32, out, inf, n, out_form);
 }
 extern "C" int32_t cheetah_multiply_vartime_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
                                                       const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
                                                       int out_form) {
-    return multiply_dev<true>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
+    return multiply_op<true>(ctx, false, pts, in_form, scalars32, out, inf, n, out_form);
 }
+extern "C" int32_t cheetah_multiply_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, uint64_t* out,
+                                          uint8_t* inf, size_t n, int out_form) {
+    return multiply_op<false>(ctx, true, pts, in_form, scalars32, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_multiply_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
+                                                  uint64_t* out, uint8_t* inf, size_t n, int out_form) {
+    return multiply_op<true>(ctx, true, pts, in_form, scalars32, out, inf, n, out_form);
+}
+
 // cheetah_multiply_batch_dev for callers that cannot allocate: the same kernels on the file-scope arena.
 // Calls no hipMalloc / hipFree (nor anything else that allocates): argument checks, hipSetDevice, kernel launches.
 // The arena needs no clearing: a workgroup writes every table entry it later reads, in every round.
+// Runs on the context's first device only (a multi-device context's other shards are not used).
 extern "C" int32_t cheetah_multiply_batch_dev_noalloc(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
                                                       uint64_t* out, uint8_t* inf, size_t n, int out_form) {
     if (!ctx) return CHEETAH_ERR_INVALID;
     if (n > (size_t)CHEETAH_NOALLOC_MAX_N)
         return fail(ctx, CHEETAH_ERR_INVALID, "cheetah_multiply_batch_dev_noalloc: n exceeds CHEETAH_NOALLOC_MAX_N (use cheetah_multiply_batch_dev)");
     if (!ctx->noalloc_arena) return fail(ctx, CHEETAH_ERR_HIP, "the static arena's device address is not known");
-    return multiply_dev<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form, ctx->noalloc_arena, NOALLOC_MAX_BLOCKS);
-}
-
-// ------------------------------------------------- host-pointer wrappers -----
-// Copy in, run the same device entry point, copy out.  PCIe-inclusive; the
-// `_dev` forms are what the benchmarks time.
-
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <class T>
-    T* as() { return static_cast<T*>(p); }
-};
-}  // namespace
-
-#define H2D(ctx, dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (ctx)->stream))
-#define D2H(ctx, dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (ctx)->stream))
-
-extern "C" int32_t cheetah_fp6_mul_batch(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!a || !b || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf da, db, dout;
-    HIP_TRY(ctx, da.alloc(n * 48));
-    HIP_TRY(ctx, db.alloc(n * 48));
-    HIP_TRY(ctx, dout.alloc(n * 48));
-    H2D(ctx, da.p, a, n * 48);
-    H2D(ctx, db.p, b, n * 48);
-    if (int32_t rc = cheetah_fp6_mul_batch_dev(ctx, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n)) return rc;
-    D2H(ctx, out, dout.p, n * 48);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-extern "C" int32_t cheetah_fp6_square_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!a || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf da, dout;
-    HIP_TRY(ctx, da.alloc(n * 48));
-    HIP_TRY(ctx, dout.alloc(n * 48));
-    H2D(ctx, da.p, a, n * 48);
-    if (int32_t rc = cheetah_fp6_square_batch_dev(ctx, da.as<u64>(), dout.as<u64>(), n)) return rc;
-    D2H(ctx, out, dout.p, n * 48);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-template <int OP>
-static int32_t fp6_option_host(cheetah_ctx* ctx, const u64* a, u64* out, u8* is_some, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!a || !out || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf da, dout, dsome;
-    HIP_TRY(ctx, da.alloc(n * 48));
-    HIP_TRY(ctx, dout.alloc(n * 48));
-    HIP_TRY(ctx, dsome.alloc(n));
-    H2D(ctx, da.p, a, n * 48);
-    if (int32_t rc = fp6_elementwise_dev<OP>(ctx, da.as<u64>(), nullptr, dout.as<u64>(), dsome.as<u8>(), n)) return rc;
-    D2H(ctx, out, dout.p, n * 48);
-    D2H(ctx, is_some, dsome.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-extern "C" int32_t cheetah_fp6_invert_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
-    return fp6_option_host<EW_INVERT>(ctx, a, out, is_some, n);
-}
-extern "C" int32_t cheetah_fp6_sqrt_batch(cheetah_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n) {
-    return fp6_option_host<EW_SQRT>(ctx, a, out, is_some, n);
-}
-
-template <int JAC>
-static int32_t batch_normalize_host(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8* inf, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!xyz || !xy || !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf din, dxy, dinf;
-    HIP_TRY(ctx, din.alloc(n * 144));
-    HIP_TRY(ctx, dxy.alloc(n * 96));
-    HIP_TRY(ctx, dinf.alloc(n));
-    H2D(ctx, din.p, xyz, n * 144);
-    if (int32_t rc = batch_normalize_dev<JAC>(ctx, din.as<u64>(), dxy.as<u64>(), dinf.as<u8>(), n)) return rc;
-    D2H(ctx, xy, dxy.p, n * 96);
-    D2H(ctx, inf, dinf.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-extern "C" int32_t cheetah_batch_normalize_projective(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
-    return batch_normalize_host<0>(ctx, xyz, xy, inf, n);
-}
-extern "C" int32_t cheetah_batch_normalize_jacobian(cheetah_ctx* ctx, const uint64_t* xyz, uint64_t* xy, uint8_t* inf, size_t n) {
-    return batch_normalize_host<1>(ctx, xyz, xy, inf, n);
-}
-
-extern "C" int32_t cheetah_mul_by_generator_batch(cheetah_ctx* ctx, const uint8_t* scalars32, uint64_t* out, uint8_t* inf, size_t n,
-                                                  int out_form) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (out_form != CHEETAH_JACOBIAN)  // BASEPOINT_LOOKUP's LookupTable<128> covers every radix-256 digit
-        for (size_t i = 0; i < n; i++)
-            if ((scalars32[32 * i + 31] >> 4) > 7)
-                return fail(ctx, CHEETAH_ERR_SCALAR, "scalar with top nibble > 7: outside BasePointTable's LookupTable<8> range");
-    const size_t w = out_form == CHEETAH_AFFINE ? 96 : 144;  // projective and Jacobian: x | y | z
-    DevBuf dsc, dout, dinf;
-    HIP_TRY(ctx, dsc.alloc(n * 32));
-    HIP_TRY(ctx, dout.alloc(n * w));
-    HIP_TRY(ctx, dinf.alloc(n));
-    H2D(ctx, dsc.p, scalars32, n * 32);
-    if (int32_t rc = cheetah_mul_by_generator_batch_dev(ctx, dsc.as<u8>(), dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
-    D2H(ctx, out, dout.p, n * w);
-    if (inf) D2H(ctx, inf, dinf.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-
-template <bool VARTIME>
-static int32_t multiply_host(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
-                             int out_form) {
-    CHECK_CTX(ctx);
     if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
     if (n == 0) return CHEETAH_OK;
-    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144, wo = out_form == CHEETAH_AFFINE ? 96 : 144;
-    DevBuf dp, dsc, dout, dinf;
-    HIP_TRY(ctx, dp.alloc(n * wi));
-    HIP_TRY(ctx, dsc.alloc(n * 32));
-    HIP_TRY(ctx, dout.alloc(n * wo));
-    HIP_TRY(ctx, dinf.alloc(n));
-    H2D(ctx, dp.p, pts, n * wi);
-    H2D(ctx, dsc.p, scalars32, n * 32);
-    if (int32_t rc = multiply_dev<VARTIME>(ctx, dp.as<u64>(), in_form, dsc.as<u8>(), dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
-    D2H(ctx, out, dout.p, n * wo);
-    if (inf) D2H(ctx, inf, dinf.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
+    if (!pts || !scalars32 || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    return multiply_impl<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form, ctx->noalloc_arena, NOALLOC_MAX_BLOCKS);
 }
-extern "C" int32_t cheetah_multiply_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, uint64_t* out,
-                                          uint8_t* inf, size_t n, int out_form) {
-    return multiply_host<false>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
-}
-extern "C" int32_t cheetah_multiply_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
-                                                  uint64_t* out, uint8_t* inf, size_t n, int out_form) {
-    return multiply_host<true>(ctx, pts, in_form, scalars32, out, inf, n, out_form);
-}
-
 
 // --------------------------------------------- multi-scalar ladders, checks -----
 
 template <bool VARTIME>
-static int32_t multiply_many_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
-                                 u64* out, u8* inf, size_t n_groups, int out_form) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
-    if (m < 1 || m > CHEETAH_MAX_MANY) return fail(ctx, CHEETAH_ERR_INVALID, "m must be in [1, CHEETAH_MAX_MANY]");
-    if (n_groups == 0) return CHEETAH_OK;
-    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
+                                  u64* out, u8* inf, size_t n_groups, int out_form) {
+    SET_DEVICE(ctx);
+    if (out_form == CHEETAH_AFFINE && !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     const int ns = m + (with_basepoint ? 1 : 0);
     int grid = lane_grid(ctx, n_groups, CH_MANY_WAVES);
     const size_t wpb = ManyScratch::words(m, ns);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * wpb)) return rc;
-    const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    const size_t in_w = form_limbs(in_form), out_w = form_limbs(out_form);
     size_t rounds = ROUNDS_PER_LAUNCH / (size_t)m;
     if (rounds == 0) rounds = 1;
     const size_t per_launch = (size_t)grid * BLOCK * rounds;
@@ -603,28 +1004,62 @@ static int32_t multiply_many_dev(cheetah_ctx* ctx, const u64* pts, int in_form, 
     return CHEETAH_OK;
 }
 
+template <bool VARTIME>
+static int32_t multiply_many_op(cheetah_ctx* ctx, bool host, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
+                                u64* out, u8* inf, size_t n_groups, int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    if (m < 1 || m > CHEETAH_MAX_MANY) return fail(ctx, CHEETAH_ERR_INVALID, "m must be in [1, CHEETAH_MAX_MANY]");
+    const size_t ns = (size_t)m + (with_basepoint ? 1 : 0);
+    Op op;
+    op.n = n_groups;
+    op.chunk = (((size_t)1 << 18) / (size_t)m + 255) / 256 * 256;
+    op.io = {in_(pts, (size_t)m * form_limbs(in_form) * 8), in_(scalars32, ns * 32), out_(out, form_limbs(out_form) * 8),
+             out_(inf, 1, out_form != CHEETAH_AFFINE)};
+    op.launch = [in_form, out_form, m, with_basepoint](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return multiply_many_impl<VARTIME>(c, at<u64>(d, 0), in_form, at<u8>(d, 1), m, with_basepoint, at<u64>(d, 2), at<u8>(d, 3), cnt,
+                                           out_form);
+    };
+    return run_op(ctx, host, op);
+}
+
 extern "C" int32_t cheetah_multiply_many_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, int m,
                                                    uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
-    return multiply_many_dev<false>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+    return multiply_many_op<false>(ctx, false, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
 }
 extern "C" int32_t cheetah_multiply_many_vartime_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
                                                            const uint8_t* scalars32, int m, uint64_t* out, uint8_t* inf,
                                                            size_t n_groups, int out_form) {
-    return multiply_many_dev<true>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+    return multiply_many_op<true>(ctx, false, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
 }
 extern "C" int32_t cheetah_multiply_double_with_basepoint_vartime_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
                                                                             const uint8_t* scalars64, uint64_t* out, uint8_t* inf,
                                                                             size_t n, int out_form) {
-    return multiply_many_dev<true>(ctx, pts, in_form, scalars64, 1, 1, out, inf, n, out_form);
+    return multiply_many_op<true>(ctx, false, pts, in_form, scalars64, 1, 1, out, inf, n, out_form);
+}
+extern "C" int32_t cheetah_multiply_many_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, int m,
+                                               uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
+    return multiply_many_op<false>(ctx, true, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+}
+extern "C" int32_t cheetah_multiply_many_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
+                                                       int m, uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
+    return multiply_many_op<true>(ctx, true, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
+}
+extern "C" int32_t cheetah_multiply_double_with_basepoint_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
+                                                                        const uint8_t* scalars64, uint64_t* out, uint8_t* inf,
+                                                                        size_t n, int out_form) {
+    return multiply_many_op<true>(ctx, true, pts, in_form, scalars64, 1, 1, out, inf, n, out_form);
 }
 
 // One fixed scalar for the whole batch through the vartime ladder (every lane has the
-// same NAF, so the wave never diverges).  out_form 3 = identity flag only.
-static int32_t fixed_scalar_dev(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* dev_scalar, u64* out, u8* inf, size_t n,
-                                int out_form) {
+// same NAF, so the wave never diverges).  out_form 3 = identity flag only; 4 = flags[i] &= is_identity.
+static int32_t fixed_scalar_impl(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* dev_scalar, u64* out, u8* inf, size_t n,
+                                 int out_form) {
+    SET_DEVICE(ctx);
+    if (!aligned8(pts) || (out && !aligned8(out))) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     int grid = lane_grid(ctx, n, CH_VT_WAVES);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
-    const size_t in_w = in_form == CHEETAH_AFFINE ? 12 : 18, out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
+    const size_t in_w = form_limbs(in_form), out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
     const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;
     const bool proj = in_form == CHEETAH_PROJECTIVE || out_form == CHEETAH_PROJECTIVE;
     for (size_t off = 0; off < n; off += per_launch) {
@@ -656,249 +1091,182 @@ static int32_t fixed_scalar_dev(cheetah_ctx* ctx, const u64* pts, int in_form, c
     return CHEETAH_OK;
 }
 
-extern "C" int32_t cheetah_is_torsion_free_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
-    CHECK_CTX(ctx);
+static int32_t is_torsion_free_op(cheetah_ctx* ctx, bool host, const u64* pts, int in_form, u8* flags, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
     if (int32_t rc = check_forms(ctx, in_form, CHEETAH_AFFINE)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!pts || !flags || !aligned8(pts)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
-    return fixed_scalar_dev(ctx, pts, in_form, ctx->fixed_scalars, nullptr, flags, n, 3);
+    Op op;
+    op.n = n;
+    op.chunk = (size_t)1 << 18;
+    op.io = {in_(pts, form_limbs(in_form) * 8), out_(flags, 1)};
+    op.launch = [in_form](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return fixed_scalar_impl(c, at<u64>(d, 0), in_form, c->fixed_scalars, nullptr, at<u8>(d, 1), cnt, 3);
+    };
+    return run_op(ctx, host, op);
+}
+static int32_t clear_cofactor_op(cheetah_ctx* ctx, bool host, const u64* pts, int in_form, u64* out, u8* inf, size_t n, int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
+    Op op;
+    op.n = n;
+    op.chunk = (size_t)1 << 18;
+    op.io = {in_(pts, form_limbs(in_form) * 8), out_(out, form_limbs(out_form) * 8), out_(inf, 1, out_form != CHEETAH_AFFINE)};
+    op.launch = [in_form, out_form](cheetah_ctx* c, void* const* d, size_t cnt) {
+        return fixed_scalar_impl(c, at<u64>(d, 0), in_form, c->fixed_scalars + 32, at<u64>(d, 1), at<u8>(d, 2), cnt, out_form);
+    };
+    return run_op(ctx, host, op);
+}
+extern "C" int32_t cheetah_is_torsion_free_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
+    return is_torsion_free_op(ctx, false, pts, in_form, flags, n);
+}
+extern "C" int32_t cheetah_is_torsion_free_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
+    return is_torsion_free_op(ctx, true, pts, in_form, flags, n);
 }
 extern "C" int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint64_t* out, uint8_t* inf,
                                                     size_t n, int out_form) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!pts || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned8(pts) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
-    return fixed_scalar_dev(ctx, pts, in_form, ctx->fixed_scalars + 32, out, inf, n, out_form);
-}
-
-// host-pointer forms
-template <bool VARTIME>
-static int32_t multiply_many_host(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
-                                  u64* out, u8* inf, size_t n_groups, int out_form) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
-    if (m < 1 || m > CHEETAH_MAX_MANY) return fail(ctx, CHEETAH_ERR_INVALID, "m must be in [1, CHEETAH_MAX_MANY]");
-    if (n_groups == 0) return CHEETAH_OK;
-    if (!pts || !scalars32 || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144, wo = out_form == CHEETAH_AFFINE ? 96 : 144;
-    const size_t ns = (size_t)m + (with_basepoint ? 1 : 0);
-    DevBuf dp, dsc, dout, dinf;
-    HIP_TRY(ctx, dp.alloc(n_groups * m * wi));
-    HIP_TRY(ctx, dsc.alloc(n_groups * ns * 32));
-    HIP_TRY(ctx, dout.alloc(n_groups * wo));
-    HIP_TRY(ctx, dinf.alloc(n_groups));
-    H2D(ctx, dp.p, pts, n_groups * m * wi);
-    H2D(ctx, dsc.p, scalars32, n_groups * ns * 32);
-    if (int32_t rc = multiply_many_dev<VARTIME>(ctx, dp.as<u64>(), in_form, dsc.as<u8>(), m, with_basepoint, dout.as<u64>(),
-                                                dinf.as<u8>(), n_groups, out_form))
-        return rc;
-    D2H(ctx, out, dout.p, n_groups * wo);
-    if (inf) D2H(ctx, inf, dinf.p, n_groups);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-extern "C" int32_t cheetah_multiply_many_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32, int m,
-                                               uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
-    return multiply_many_host<false>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
-}
-extern "C" int32_t cheetah_multiply_many_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, const uint8_t* scalars32,
-                                                       int m, uint64_t* out, uint8_t* inf, size_t n_groups, int out_form) {
-    return multiply_many_host<true>(ctx, pts, in_form, scalars32, m, 0, out, inf, n_groups, out_form);
-}
-extern "C" int32_t cheetah_multiply_double_with_basepoint_vartime_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form,
-                                                                        const uint8_t* scalars64, uint64_t* out, uint8_t* inf,
-                                                                        size_t n, int out_form) {
-    return multiply_many_host<true>(ctx, pts, in_form, scalars64, 1, 1, out, inf, n, out_form);
-}
-extern "C" int32_t cheetah_is_torsion_free_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, in_form, CHEETAH_AFFINE)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!pts || !flags) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144;
-    DevBuf dp, df;
-    HIP_TRY(ctx, dp.alloc(n * wi));
-    HIP_TRY(ctx, df.alloc(n));
-    H2D(ctx, dp.p, pts, n * wi);
-    if (int32_t rc = cheetah_is_torsion_free_batch_dev(ctx, dp.as<u64>(), in_form, df.as<u8>(), n)) return rc;
-    D2H(ctx, flags, df.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
+    return clear_cofactor_op(ctx, false, pts, in_form, out, inf, n, out_form);
 }
 extern "C" int32_t cheetah_clear_cofactor_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint64_t* out, uint8_t* inf,
                                                 size_t n, int out_form) {
-    CHECK_CTX(ctx);
-    if (int32_t rc = check_forms(ctx, in_form, out_form)) return rc;
-    if (n == 0) return CHEETAH_OK;
-    if (!pts || !out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    const size_t wi = in_form == CHEETAH_AFFINE ? 96 : 144, wo = out_form == CHEETAH_AFFINE ? 96 : 144;
-    DevBuf dp, dout, dinf;
-    HIP_TRY(ctx, dp.alloc(n * wi));
-    HIP_TRY(ctx, dout.alloc(n * wo));
-    HIP_TRY(ctx, dinf.alloc(n));
-    H2D(ctx, dp.p, pts, n * wi);
-    if (int32_t rc = cheetah_clear_cofactor_batch_dev(ctx, dp.as<u64>(), in_form, dout.as<u64>(), dinf.as<u8>(), n, out_form)) return rc;
-    D2H(ctx, out, dout.p, n * wo);
-    if (inf) D2H(ctx, inf, dinf.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
+    return clear_cofactor_op(ctx, true, pts, in_form, out, inf, n, out_form);
 }
 
+static int ew_grid(const cheetah_ctx* c, size_t n) {
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)c->num_cus * 8;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+static int32_t is_on_curve_op(cheetah_ctx* ctx, bool host, const u64* pts, int in_form, u8* flags, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, in_form, CHEETAH_AFFINE)) return rc;
+    Op op;
+    op.n = n;
+    op.io = {in_(pts, form_limbs(in_form) * 8), out_(flags, 1)};
+    op.launch = [in_form](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0])) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        const int grid = ew_grid(c, cnt);
+        if (in_form == CHEETAH_AFFINE)
+            hipLaunchKernelGGL((k_is_on_curve<0>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u8>(d, 1), cnt);
+        else if (in_form == CHEETAH_PROJECTIVE)
+            hipLaunchKernelGGL((k_is_on_curve<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u8>(d, 1), cnt);
+        else
+            hipLaunchKernelGGL((k_is_on_curve<2>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u8>(d, 1), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
+extern "C" int32_t cheetah_is_on_curve_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
+    return is_on_curve_op(ctx, false, pts, in_form, flags, n);
+}
+extern "C" int32_t cheetah_is_on_curve_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint8_t* flags, size_t n) {
+    return is_on_curve_op(ctx, true, pts, in_form, flags, n);
+}
 
 // -------------------------------------------------------------- encodings -----
 
-static bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
-
 template <int REC>
-static int32_t encode_dev(cheetah_ctx* ctx, const u64* xy, const u8* inf, u8* out, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!xy || !inf || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned16(xy) || !aligned4(out)) return fail(ctx, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
-    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
-    hipLaunchKernelGGL((k_encode<REC>), dim3((int)(tiles < cap ? tiles : cap)), dim3(BLOCK), 0, ctx->stream, xy, inf, out, n);
-    HIP_TRY(ctx, hipGetLastError());
-    return CHEETAH_OK;
+static int32_t encode_op(cheetah_ctx* ctx, bool host, const u64* xy, const u8* inf, u8* out, size_t n) {
+    Op op;
+    op.n = n;
+    op.io = {in_(xy, 96), in_(inf, 1), out_(out, REC)};
+    op.launch = [](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned16(d[0]) || !aligned4(d[2])) return fail(c, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
+        hipLaunchKernelGGL((k_encode<REC>), dim3(ew_grid(c, cnt)), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u8>(d, 1), at<u8>(d, 2), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
 }
 extern "C" int32_t cheetah_encode_uncompressed_batch_dev(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out97, size_t n) {
-    return encode_dev<97>(ctx, xy, inf, out97, n);
+    return encode_op<97>(ctx, false, xy, inf, out97, n);
 }
 extern "C" int32_t cheetah_encode_compressed_batch_dev(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out49, size_t n) {
-    return encode_dev<49>(ctx, xy, inf, out49, n);
+    return encode_op<49>(ctx, false, xy, inf, out49, n);
+}
+extern "C" int32_t cheetah_encode_uncompressed_batch(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out97, size_t n) {
+    return encode_op<97>(ctx, true, xy, inf, out97, n);
+}
+extern "C" int32_t cheetah_encode_compressed_batch(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out49, size_t n) {
+    return encode_op<49>(ctx, true, xy, inf, out49, n);
+}
+
+template <int REC>
+static int32_t decode_op(cheetah_ctx* ctx, bool host, const u8* in, u64* xy, u8* inf, u8* is_some, size_t n, int checked) {
+    Op op;
+    op.n = n;
+    op.chunk = checked ? (size_t)1 << 18 : (size_t)1 << 20;
+    op.io = {in_(in, REC), out_(xy, 96), out_(inf, 1), out_(is_some, 1)};
+    op.launch = [checked](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        const u8* src = at<u8>(d, 0);
+        u64* pxy = at<u64>(d, 1);
+        u8 *pinf = at<u8>(d, 2), *psome = at<u8>(d, 3);
+        if (!aligned16(pxy) || !aligned4(src)) return fail(c, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
+        const int grid = ew_grid(c, cnt);
+        if (REC == 97) {
+            if (checked)
+                hipLaunchKernelGGL((k_decode_uncompressed<1>), dim3(grid), dim3(BLOCK), 0, c->stream, src, pxy, pinf, psome, cnt);
+            else
+                hipLaunchKernelGGL((k_decode_uncompressed<0>), dim3(grid), dim3(BLOCK), 0, c->stream, src, pxy, pinf, psome, cnt);
+        } else {
+            hipLaunchKernelGGL(k_decode_compressed, dim3(grid), dim3(BLOCK), 0, c->stream, src, pxy, pinf, psome, cnt);
+        }
+        HIP_TRY(c, hipGetLastError());
+        if (checked) {  // is_some &= is_torsion_free, then rejected records leave as (0, 0, inf = 0)
+            if (int32_t rc = fixed_scalar_impl(c, pxy, CHEETAH_AFFINE, c->fixed_scalars, nullptr, psome, cnt, 4)) return rc;
+            hipLaunchKernelGGL(k_zero_rejected, dim3(grid), dim3(BLOCK), 0, c->stream, pxy, pinf, psome, cnt);
+            HIP_TRY(c, hipGetLastError());
+        }
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
 }
 extern "C" int32_t cheetah_decode_uncompressed_batch_dev(cheetah_ctx* ctx, const uint8_t* in97, uint64_t* xy, uint8_t* inf,
                                                          uint8_t* is_some, size_t n, int checked) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!in97 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned16(xy) || !aligned4(in97)) return fail(ctx, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
-    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
-    int grid = (int)(tiles < cap ? tiles : cap);
-    if (checked) {
-        hipLaunchKernelGGL((k_decode_uncompressed<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, in97, xy, inf, is_some, n);
-        HIP_TRY(ctx, hipGetLastError());
-        if (int32_t rc = fixed_scalar_dev(ctx, xy, CHEETAH_AFFINE, ctx->fixed_scalars, nullptr, is_some, n, 4)) return rc;  // is_some &= is_torsion_free
-        hipLaunchKernelGGL(k_zero_rejected, dim3(grid), dim3(BLOCK), 0, ctx->stream, xy, inf, is_some, n);
-        HIP_TRY(ctx, hipGetLastError());
-        return CHEETAH_OK;
-    }
-    hipLaunchKernelGGL((k_decode_uncompressed<0>), dim3(grid), dim3(BLOCK), 0, ctx->stream, in97, xy, inf, is_some, n);
-    HIP_TRY(ctx, hipGetLastError());
-    return CHEETAH_OK;
+    return decode_op<97>(ctx, false, in97, xy, inf, is_some, n, checked);
 }
-
 extern "C" int32_t cheetah_decode_compressed_batch_dev(cheetah_ctx* ctx, const uint8_t* in49, uint64_t* xy, uint8_t* inf,
                                                        uint8_t* is_some, size_t n, int checked) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!in49 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned16(xy) || !aligned4(in49)) return fail(ctx, CHEETAH_ERR_INVALID, "xy must be 16-byte aligned, the byte array 4-byte aligned");
-    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
-    int grid = (int)(tiles < cap ? tiles : cap);
-    hipLaunchKernelGGL(k_decode_compressed, dim3(grid), dim3(BLOCK), 0, ctx->stream, in49, xy, inf, is_some, n);
-    HIP_TRY(ctx, hipGetLastError());
-    if (checked) {
-        if (int32_t rc = fixed_scalar_dev(ctx, xy, CHEETAH_AFFINE, ctx->fixed_scalars, nullptr, is_some, n, 4)) return rc;  // is_some &= is_torsion_free
-        hipLaunchKernelGGL(k_zero_rejected, dim3(grid), dim3(BLOCK), 0, ctx->stream, xy, inf, is_some, n);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    return CHEETAH_OK;
-}
-extern "C" int32_t cheetah_affine_from_x_batch_dev(cheetah_ctx* ctx, const uint64_t* x, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
-                                                   size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!x || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    if (!aligned16(x) || !aligned16(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
-    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)ctx->num_cus * 8;
-    hipLaunchKernelGGL(k_affine_from_x, dim3((int)(tiles < cap ? tiles : cap)), dim3(BLOCK), 0, ctx->stream, x, xy, inf, is_some, n);
-    HIP_TRY(ctx, hipGetLastError());
-    return CHEETAH_OK;
-}
-
-template <int REC>
-static int32_t encode_host(cheetah_ctx* ctx, const u64* xy, const u8* inf, u8* out, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!xy || !inf || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf dxy, dinf, dout;
-    HIP_TRY(ctx, dxy.alloc(n * 96));
-    HIP_TRY(ctx, dinf.alloc(n));
-    HIP_TRY(ctx, dout.alloc(n * REC));
-    H2D(ctx, dxy.p, xy, n * 96);
-    H2D(ctx, dinf.p, inf, n);
-    if (int32_t rc = encode_dev<REC>(ctx, dxy.as<u64>(), dinf.as<u8>(), dout.as<u8>(), n)) return rc;
-    D2H(ctx, out, dout.p, n * REC);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
-}
-extern "C" int32_t cheetah_encode_uncompressed_batch(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out97, size_t n) {
-    return encode_host<97>(ctx, xy, inf, out97, n);
-}
-extern "C" int32_t cheetah_encode_compressed_batch(cheetah_ctx* ctx, const uint64_t* xy, const uint8_t* inf, uint8_t* out49, size_t n) {
-    return encode_host<49>(ctx, xy, inf, out49, n);
+    return decode_op<49>(ctx, false, in49, xy, inf, is_some, n, checked);
 }
 extern "C" int32_t cheetah_decode_uncompressed_batch(cheetah_ctx* ctx, const uint8_t* in97, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
                                                      size_t n, int checked) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!in97 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf din, dxy, dinf, dsome;
-    HIP_TRY(ctx, din.alloc(n * 97));
-    HIP_TRY(ctx, dxy.alloc(n * 96));
-    HIP_TRY(ctx, dinf.alloc(n));
-    HIP_TRY(ctx, dsome.alloc(n));
-    H2D(ctx, din.p, in97, n * 97);
-    if (int32_t rc = cheetah_decode_uncompressed_batch_dev(ctx, din.as<u8>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n, checked)) return rc;
-    D2H(ctx, xy, dxy.p, n * 96);
-    D2H(ctx, inf, dinf.p, n);
-    D2H(ctx, is_some, dsome.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
+    return decode_op<97>(ctx, true, in97, xy, inf, is_some, n, checked);
 }
-
 extern "C" int32_t cheetah_decode_compressed_batch(cheetah_ctx* ctx, const uint8_t* in49, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
                                                    size_t n, int checked) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!in49 || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf din, dxy, dinf, dsome;
-    HIP_TRY(ctx, din.alloc(n * 49));
-    HIP_TRY(ctx, dxy.alloc(n * 96));
-    HIP_TRY(ctx, dinf.alloc(n));
-    HIP_TRY(ctx, dsome.alloc(n));
-    H2D(ctx, din.p, in49, n * 49);
-    if (int32_t rc = cheetah_decode_compressed_batch_dev(ctx, din.as<u8>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n, checked)) return rc;
-    D2H(ctx, xy, dxy.p, n * 96);
-    D2H(ctx, inf, dinf.p, n);
-    D2H(ctx, is_some, dsome.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
+    return decode_op<49>(ctx, true, in49, xy, inf, is_some, n, checked);
+}
+
+static int32_t affine_from_x_op(cheetah_ctx* ctx, bool host, const u64* x, u64* xy, u8* inf, u8* is_some, size_t n) {
+    Op op;
+    op.n = n;
+    op.io = {in_(x, 48), out_(xy, 96), out_(inf, 1), out_(is_some, 1)};
+    op.launch = [](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned16(d[0]) || !aligned16(d[1])) return fail(c, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
+        hipLaunchKernelGGL(k_affine_from_x, dim3(ew_grid(c, cnt)), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), at<u8>(d, 2),
+                           at<u8>(d, 3), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
+extern "C" int32_t cheetah_affine_from_x_batch_dev(cheetah_ctx* ctx, const uint64_t* x, uint64_t* xy, uint8_t* inf, uint8_t* is_some,
+                                                   size_t n) {
+    return affine_from_x_op(ctx, false, x, xy, inf, is_some, n);
 }
 extern "C" int32_t cheetah_affine_from_x_batch(cheetah_ctx* ctx, const uint64_t* x, uint64_t* xy, uint8_t* inf, uint8_t* is_some, size_t n) {
-    CHECK_CTX(ctx);
-    if (n == 0) return CHEETAH_OK;
-    if (!x || !xy || !inf || !is_some) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    DevBuf dx, dxy, dinf, dsome;
-    HIP_TRY(ctx, dx.alloc(n * 48));
-    HIP_TRY(ctx, dxy.alloc(n * 96));
-    HIP_TRY(ctx, dinf.alloc(n));
-    HIP_TRY(ctx, dsome.alloc(n));
-    H2D(ctx, dx.p, x, n * 48);
-    if (int32_t rc = cheetah_affine_from_x_batch_dev(ctx, dx.as<u64>(), dxy.as<u64>(), dinf.as<u8>(), dsome.as<u8>(), n)) return rc;
-    D2H(ctx, xy, dxy.p, n * 96);
-    D2H(ctx, inf, dinf.p, n);
-    D2H(ctx, is_some, dsome.p, n);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return CHEETAH_OK;
+    return affine_from_x_op(ctx, true, x, xy, inf, is_some, n);
 }
 
 // ------------------------------------------------------- tables, synth -----
 
 extern "C" int32_t cheetah_read_table(cheetah_ctx* ctx, int which, uint64_t* out_xy, size_t max_points) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     if (!out_xy) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     const char* base = reinterpret_cast<const char*>(ctx->tables);
     size_t off, pts;
@@ -924,7 +1292,8 @@ extern "C" int32_t cheetah_read_table(cheetah_ctx* ctx, int which, uint64_t* out
 }
 
 extern "C" int32_t cheetah_synth_fp6_dev(cheetah_ctx* ctx, uint64_t seed, uint64_t start, uint64_t* out, size_t n) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     if (n == 0) return CHEETAH_OK;
     if (!out || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
     hipLaunchKernelGGL(k_synth_fp6, dim3(ctx->num_cus * 8), dim3(BLOCK), 0, ctx->stream, seed, start, out, n * 6);
@@ -932,7 +1301,8 @@ extern "C" int32_t cheetah_synth_fp6_dev(cheetah_ctx* ctx, uint64_t seed, uint64
     return CHEETAH_OK;
 }
 extern "C" int32_t cheetah_synth_scalars_dev(cheetah_ctx* ctx, uint64_t seed, uint64_t start, uint8_t* out32, size_t n) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     if (n == 0) return CHEETAH_OK;
     if (!out32 || !aligned8(out32)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
     hipLaunchKernelGGL(k_synth_scalars, dim3(ctx->num_cus * 8), dim3(BLOCK), 0, ctx->stream, seed, start,
@@ -944,7 +1314,8 @@ extern "C" int32_t cheetah_synth_scalars_dev(cheetah_ctx* ctx, uint64_t seed, ui
 // ---------------------------------------------------------- diagnostics -----
 
 extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     if (n == 0) return CHEETAH_OK;
     if (!a || !out) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     hipLaunchKernelGGL(k_debug_op, dim3(lane_grid(ctx, n, 4)), dim3(BLOCK), 0, ctx->stream, op, a, b, out, n);
@@ -952,14 +1323,8 @@ extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t
     return CHEETAH_OK;
 }
 
-extern "C" int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx* ctx, int cus) {
-    CHECK_CTX(ctx);
-    if (cus < 0 || cus >= ctx->num_cus) return fail(ctx, CHEETAH_ERR_INVALID, "reserved CUs must be in [0, number of CUs)");
-    ctx->reserved_cus = cus;
-    return CHEETAH_OK;
-}
 extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n, int vartime, int out_form, size_t* units) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
     if (!units) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     const int waves = (vartime && out_form != CHEETAH_AFFINE) ? CH_VT_WAVES : CH_CT_WAVES;
     const size_t per_launch = (size_t)lane_grid(ctx, n ? n : 1, waves) * BLOCK * ROUNDS_PER_LAUNCH;
@@ -967,10 +1332,10 @@ extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n,
     return CHEETAH_OK;
 }
 extern "C" int32_t cheetah_calibrate_mad_peak(cheetah_ctx* ctx, double* tera_mads_per_s) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     if (!tera_mads_per_s) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    u64* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, 64));
+    u64* d = ctx->scratch;  // the kernel stores at most one word, and only for a value that does not occur
     const int iters = 4096, blocks = ctx->num_cus * 8;
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
@@ -982,18 +1347,19 @@ extern "C" int32_t cheetah_calibrate_mad_peak(cheetah_ctx* ctx, double* tera_mad
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         if (rep > 0 && ms < best) best = ms;
     }
-    HIP_TRY(ctx, hipFree(d));
     *tera_mads_per_s = (double)blocks * BLOCK * 64.0 * iters / (best * 1e-3) / 1e12;
     return CHEETAH_OK;
 }
 
 extern "C" int32_t cheetah_timer_start(cheetah_ctx* ctx) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return CHEETAH_OK;
 }
 extern "C" int32_t cheetah_timer_stop_ms(cheetah_ctx* ctx, float* ms) {
-    CHECK_CTX(ctx);
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    SET_DEVICE(ctx);
     if (!ms) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

@@ -152,9 +152,31 @@ template <> struct Ladder<MJac> {
     static CH_DEV MJac add_last(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<false>(p, q); }
 };
 
+// (0, 1) is the affine encoding of the identity (src/curve/affine.rs:224-230); it is not a point of the curve
+// (1 != B), so the encoding is unambiguous.
+CH_DEV bool affine_is_identity_encoding(const Fp6& x, const Fp6& y) {
+    return fp6_is_zero(x) && fp_canonical(y.c[0]) == 1 && fp_is_zero(y.c[1]) && fp_is_zero(y.c[2]) && fp_is_zero(y.c[3]) &&
+           fp_is_zero(y.c[4]) && fp_is_zero(y.c[5]);
+}
+
+// The point whose multiples fill the window table, as a projective point:
+//   affine input     ProjectivePoint::from(&AffinePoint)              src/curve/projective.rs:102-110
+//   projective input as is
+//   Jacobian input   LookupTable::from(&JacobianPoint) normalises first: AffinePoint::from(p),
+//                    one Fp6 inversion                                src/lookup.rs:45-49, src/curve/affine.rs:86-101
+template <int IN_FORM>
+CH_DEV Proj load_input_point(const u64* pts, size_t i) {
+    if (IN_FORM == 0) {
+        Affine a = load_affine(pts + 12 * i);
+        a.inf = affine_is_identity_encoding(a.x, a.y);
+        return proj_from_affine(a);
+    }
+    if (IN_FORM == 2) return proj_from_affine(affine_from_jac(load_proj(pts + 18 * i)));
+    return load_proj(pts + 18 * i);
+}
+
 // ---------------------------------------------------------------------------
-// Table construction (context creation).  Thread t < 32 builds LookupTable<8> of
-// 256^t G (src/lookup.rs:164-173, :25-37); thread 32 builds -2^4 S and -2^256 S
+// Table construction (context creation).  Thread 32 builds -2^4 S and -2^256 S
 // (src/constants.rs:80-90); thread 64 + e builds entry (e + 1) G of
 // BASEPOINT_LOOKUP (src/constants.rs:26-27); thread 192 + e builds entry (2e + 1) G of
 // ODD_MULTIPLES_BASEPOINT (src/constants.rs:32-33).  Entries are affine, hence
@@ -163,14 +185,7 @@ constexpr int BUILD_TABLES_THREADS = 256;
 __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTables* tab, const u64* gen_xy, const u64* shift_xy) {
     const int t = threadIdx.x;
     if (t < 32) {
-        Proj base = proj_from_affine(load_affine(gen_xy));
-        for (int i = 0; i < 8 * t; i++) base = proj_double(base);
-        Proj cur = base;
-        for (int j = 0; j < 8; j++) {
-            if (j > 0) cur = proj_add(base, cur);
-            Affine a = affine_from_proj(cur);
-            store_affine(tab->basepoint, nullptr, (size_t)(8 * t + j), a);
-        }
+        // BASEPOINT_TABLE itself is built by k_build_comb_table (shared with BasePointTable::create for any base)
     } else if (t == 32) {
         Affine s = load_affine(shift_xy);
         store_affine(tab->shift, nullptr, 0, s);
@@ -208,6 +223,22 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
             store_affine(tab->odd_multiples, nullptr, (size_t)(t - 192), affine_from_proj(acc));
         else
             store_affine(tab->basepoint_lookup, nullptr, (size_t)(m - 1), affine_from_proj(acc));
+    }
+}
+
+// BasePointTable::create (src/lookup.rs:164-173): thread t builds LookupTable<8> of 256^t P (:25-37): eight
+// multiples by the complete addition, affine (identities stored as (0, 1)).  Entries are affine, hence independent
+// of how they were computed.  Used for BASEPOINT_TABLE (P = G) and for caller-supplied bases.
+template <int IN_FORM>
+__global__ void __launch_bounds__(64) k_build_comb_table(u64* comb /* [32][8][12] */, const u64* base_pt) {
+    const int t = threadIdx.x;
+    if (t >= 32) return;
+    Proj base = load_input_point<IN_FORM>(base_pt, 0);
+    for (int i = 0; i < 8 * t; i++) base = proj_double(base);
+    Proj cur = base;
+    for (int j = 0; j < 8; j++) {
+        if (j > 0) cur = proj_add(base, cur);
+        store_affine(comb, nullptr, (size_t)(8 * t + j), affine_from_proj(cur));
     }
 }
 
@@ -425,6 +456,8 @@ CH_DEV void load_scalar(const u8* scalars, size_t i, u64 k[4]) {
 // entries of the digit's sub-table (every lane the same addresses: an LDS
 // broadcast) and keeps the one it wants by selects -- the reference's
 // constant-time scan (src/lookup.rs:81-102).
+// GENERIC: the table may hold identities (a caller-supplied base of small order), stored as (0, 1).
+template <bool GENERIC = false>
 CH_DEV Affine lds_lookup8(const u64* sub /* 8 x 12 limbs in LDS */, int d) {
     const int neg = d < 0;
     const int dabs = neg ? -d : d;
@@ -440,17 +473,25 @@ CH_DEV Affine lds_lookup8(const u64* sub /* 8 x 12 limbs in LDS */, int d) {
         }
         t.inf = hit ? false : t.inf;
     }
+    if (GENERIC) t.inf = t.inf || affine_is_identity_encoding(t.x, t.y);
     return affine_cond_neg(t, neg);
 }
 
-template <int OUT_FORM>
+// A scalar outside what BasePointTable's LookupTable<8> covers (top nibble > 7): the element is
+// rejected, whatever the output form: limbs zeroed, inf = 0xFF.
+CH_DEV void store_rejected(u64* out, u8* inf, size_t i, int width) {
+    for (int l = 0; l < width; l++) out[(size_t)width * i + l] = 0;
+    inf[i] = 0xFF;
+}
+
+template <int OUT_FORM, bool GENERIC = false>
 __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const DeviceTables* __restrict__ tab,
-                                                            const u8* __restrict__ scalars, u64* __restrict__ out,
-                                                            u8* __restrict__ inf, size_t n) {
+                                                            const u64* __restrict__ comb, const u8* __restrict__ scalars,
+                                                            u64* __restrict__ out, u8* __restrict__ inf, size_t n) {
     __shared__ u64 s_tab[32 * 8 * 12];
     __shared__ i8 s_digits[64 * BLOCK];
     const int t = threadIdx.x;
-    for (int w = t; w < 32 * 8 * 12; w += BLOCK) s_tab[w] = tab->basepoint[w];
+    for (int w = t; w < 32 * 8 * 12; w += BLOCK) s_tab[w] = comb[w];
     const Affine shift = load_affine(tab->shift);
     const Affine mshift4 = load_affine(tab->minus_shift_4);
     const size_t nround = (n + BLOCK - 1) / BLOCK;
@@ -464,13 +505,15 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const 
         __syncthreads();
         const bool in_range = (k[3] >> 60) <= 7;  // LookupTable<8> covers the top digit only then (Q3)
         Proj acc = proj_from_affine(shift);
-        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8<GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
         for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
-        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8<GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
         acc = proj_add_mixed_unchecked(acc, mshift4);
         if (active) {
-            emit_point<OUT_FORM>(out, inf, i, acc);
-            if (!in_range && inf) inf[i] = 0xFF;
+            if (in_range)
+                emit_point<OUT_FORM>(out, inf, i, acc);
+            else
+                store_rejected(out, inf, i, OUT_FORM == 0 ? 12 : 18);
         }
     }
 }
@@ -486,10 +529,11 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const 
 // (constant time, as the reference's scan, src/lookup.rs:81-102).  The accumulator starts from
 // the shift point S and S is subtracted at the end, so the incomplete addition never meets the
 // identity (the reference's own device, src/lookup.rs:196, :205).  Digits are recoded on the fly.
-__global__ void __launch_bounds__(64) k_build_wide_table(DeviceTables* tab, const u64* gen_xy) {
-    const int j = blockIdx.x, e = threadIdx.x;  // entry (e + 1) 64^j G
+template <int IN_FORM>
+__global__ void __launch_bounds__(64) k_build_wide_table(u64* wide /* [43][32][12] */, const u64* base_pt) {
+    const int j = blockIdx.x, e = threadIdx.x;  // entry (e + 1) 64^j P
     if (e >= WIDE_ENTRIES) return;
-    Proj base = proj_from_affine(load_affine(gen_xy));
+    Proj base = load_input_point<IN_FORM>(base_pt, 0);
     for (int i = 0; i < WIDE_BITS * j; i++) base = proj_double(base);
     Proj acc = proj_identity();
     for (int b = 5; b >= 0; b--) {  // (e + 1) <= 32 by left-to-right double-and-add, complete formulas
@@ -497,9 +541,10 @@ __global__ void __launch_bounds__(64) k_build_wide_table(DeviceTables* tab, cons
         Proj sum = proj_add(acc, base);
         if (((e + 1) >> b) & 1) acc = sum;
     }
-    store_affine(tab->wide, nullptr, (size_t)(j * WIDE_ENTRIES + e), affine_from_proj(acc));
+    store_affine(wide, nullptr, (size_t)(j * WIDE_ENTRIES + e), affine_from_proj(acc));
 }
 
+template <bool GENERIC = false>
 CH_DEV Affine lds_lookup32(const u64* sub /* 32 x 12 limbs in LDS */, int d) {
     const int neg = d < 0;
     const int dabs = neg ? -d : d;
@@ -515,15 +560,18 @@ CH_DEV Affine lds_lookup32(const u64* sub /* 32 x 12 limbs in LDS */, int d) {
         }
         t.inf = hit ? false : t.inf;
     }
+    if (GENERIC) t.inf = t.inf || affine_is_identity_encoding(t.x, t.y);
     return affine_cond_neg(t, neg);
 }
 
+template <bool GENERIC = false>
 __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const DeviceTables* __restrict__ tab,
+                                                                        const u64* __restrict__ wide,
                                                                         const u8* __restrict__ scalars, u64* __restrict__ out,
                                                                         u8* __restrict__ inf, size_t n) {
     __shared__ u64 s_wide[WIDE_WINDOWS * WIDE_ENTRIES * 12];
     const int t = threadIdx.x;
-    for (int w = t; w < WIDE_WINDOWS * WIDE_ENTRIES * 12; w += WIDE_BLOCK) s_wide[w] = tab->wide[w];
+    for (int w = t; w < WIDE_WINDOWS * WIDE_ENTRIES * 12; w += WIDE_BLOCK) s_wide[w] = wide[w];
     const Affine shift = load_affine(tab->shift);
     __syncthreads();
     const size_t nround = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
@@ -544,12 +592,14 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const D
             k[1] = (k[1] >> 6) | (k[2] << 58);
             k[2] = (k[2] >> 6) | (k[3] << 58);
             k[3] >>= 6;
-            acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, lds_lookup32(s_wide + j * (WIDE_ENTRIES * 12), d));
+            acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, lds_lookup32<GENERIC>(s_wide + j * (WIDE_ENTRIES * 12), d));
         }
         acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, affine_cond_neg(shift, true));
         if (active) {
-            emit_point<0>(out, inf, i, acc);
-            if (!in_range) inf[i] = 0xFF;
+            if (in_range)
+                emit_point<0>(out, inf, i, acc);
+            else
+                store_rejected(out, inf, i, 12);
         }
     }
 }
@@ -699,24 +749,6 @@ CH_DEV Affine scan_lookup(const u64* s_tab, int n_entries, u32 ident, int d, int
         r.inf = hit ? (bool)((ident >> (j - 1)) & 1) : r.inf;
     }
     return affine_cond_neg(r, neg);
-}
-
-// The point whose multiples fill the window table, as a projective point:
-//   affine input     ProjectivePoint::from(&AffinePoint)              src/curve/projective.rs:102-110
-//   projective input as is
-//   Jacobian input   LookupTable::from(&JacobianPoint) normalises first: AffinePoint::from(p),
-//                    one Fp6 inversion                                src/lookup.rs:45-49, src/curve/affine.rs:86-101
-template <int IN_FORM>
-CH_DEV Proj load_input_point(const u64* pts, size_t i) {
-    if (IN_FORM == 0) {
-        Affine a = load_affine(pts + 12 * i);
-        // (0, 1) is the affine encoding of the identity (src/curve/affine.rs:224-230)
-        a.inf = fp6_is_zero(a.x) && fp_canonical(a.y.c[0]) == 1 && fp_is_zero(a.y.c[1]) && fp_is_zero(a.y.c[2]) &&
-                fp_is_zero(a.y.c[3]) && fp_is_zero(a.y.c[4]) && fp_is_zero(a.y.c[5]);
-        return proj_from_affine(a);
-    }
-    if (IN_FORM == 2) return proj_from_affine(affine_from_jac(load_proj(pts + 18 * i)));
-    return load_proj(pts + 18 * i);
 }
 
 // Variable-time lookup (LookupTable::get_point_vartime, src/lookup.rs:107-126): entry |d| by index.
@@ -1215,6 +1247,39 @@ __global__ void __launch_bounds__(BLOCK) k_zero_rejected(u64* __restrict__ xy, u
             xy[w] = 0;
             if (w == e * 12) inf[e] = 0;
         }
+    }
+}
+
+// is_on_curve: AffinePoint (FORM 0, src/curve/affine.rs:364-368: y^2 - x (x^2 + 1) == B, or the identity),
+// ProjectivePoint (FORM 1, src/curve/projective.rs:940-946: Y^2 Z == X^3 + X Z^2 + B Z^3, or Z == 0),
+// JacobianPoint (FORM 2, src/curve/jacobian.rs:930-938: Y^2 == X^3 + X Z^4 + B Z^6, or Z == 0).
+CH_DEV Fp6 curve_b() {  // B = u + 395, src/curve/mod.rs:42-49
+    Fp6 b = fp6_zero();
+    b.c[0] = 395;
+    b.c[1] = 1;
+    return b;
+}
+template <int FORM>
+__global__ void __launch_bounds__(BLOCK) k_is_on_curve(const u64* __restrict__ pts, u8* __restrict__ flags, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        bool ok;
+        if (FORM == 0) {
+            const Affine p = load_affine(pts + 12 * i);
+            const Fp6 lhs = fp6_sub(fp6_square(p.y), fp6_mul(p.x, fp6_add(fp6_square(p.x), fp6_one())));
+            ok = fp6_eq(lhs, curve_b()) || affine_is_identity_encoding(p.x, p.y);
+        } else {
+            const Proj p = load_proj(pts + 18 * i);
+            const Fp6 x3 = fp6_mul(fp6_square(p.x), p.x), z2 = fp6_square(p.z);
+            if (FORM == 1) {
+                const Fp6 rhs = fp6_add(fp6_add(x3, fp6_mul(p.x, z2)), fp6_mul(fp6_mul(z2, p.z), curve_b()));
+                ok = fp6_eq(fp6_mul(fp6_square(p.y), p.z), rhs) || fp6_is_zero(p.z);
+            } else {
+                const Fp6 z4 = fp6_square(z2);
+                const Fp6 rhs = fp6_add(fp6_add(x3, fp6_mul(p.x, z4)), fp6_mul(fp6_mul(z2, z4), curve_b()));
+                ok = fp6_eq(fp6_square(p.y), rhs) || fp6_is_zero(p.z);
+            }
+        }
+        flags[i] = ok ? 1 : 0;
     }
 }
 

@@ -32,17 +32,29 @@ def _is_torch(x):
 
 
 class Engine:
-    """One context = one GPU (cheetah_ctx).  Builds BASEPOINT_TABLE and the shift
-    points on the device at construction (src/constants.rs:21-22, :43-90)."""
+    """One context (cheetah_ctx) on one GPU, or on several: `device` is a device id or a list of ids.
+    Builds BASEPOINT_TABLE and the shift points on every device at construction
+    (src/constants.rs:21-22, :43-90).  With several devices every call shards its batch contiguously
+    over them and gathers the results (host arrays, or tensors of the first device).
+    `replicate=k` (tests only) puts k shards on ONE device to exercise that path on a one-GPU box."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, replicate=0):
         self._lib = _capi.load()
-        self.device = int(device)
+        ids = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+        self.devices = ids
+        self.device = ids[0] if ids else 0
         h = C.c_void_p()
-        rc = self._lib.cheetah_ctx_create(self.device, C.byref(h))
+        if replicate:
+            rc = self._lib.cheetah_debug_ctx_create_replicated(self.device, int(replicate), C.byref(h))
+        else:
+            rc = self._lib.cheetah_ctx_create((C.c_int * len(ids))(*ids), len(ids), C.byref(h))
         if rc != 0:
             raise CheetahError(rc, self._lib.cheetah_last_error(None).decode())
         self._h = h
+
+    @property
+    def num_devices(self):
+        return self._lib.cheetah_ctx_num_devices(self._h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -226,6 +238,35 @@ class Engine:
         (src/curve/projective.rs:633-662) or JacobianPoint / AffinePoint::multiply_vartime
         (src/curve/jacobian.rs:619-649), chosen by the forms as in multiply_batch."""
         return self._multiply(True, pts, scalars, in_form, out_form, out, inf)
+
+    def multiply_batch_noalloc(self, pts, scalars, in_form=AFFINE, out_form=AFFINE, out=None, inf=None):
+        """multiply_batch on device tensors through the entry point that allocates nothing
+        (cheetah_multiply_batch_dev_noalloc): `out` and `inf` must be given."""
+        w, wi = self._out_width(out_form), self._out_width(in_form)
+        p, s = self._dev(pts, 8, wi), self._dev(scalars, 1, 32)
+        out = self._dev(out, 8, w)
+        self._use_torch_stream()
+        self._check(self._lib.cheetah_multiply_batch_dev_noalloc(self._h, p.data_ptr(), in_form, s.data_ptr(), out.data_ptr(),
+                                                                 inf.data_ptr(), s.shape[0], out_form))
+        return out, inf
+
+    def basepoint_table(self, point, in_form=AFFINE):
+        """BasePointTable::create(&P) (src/lookup.rs:164-173) for one caller-supplied point (host array)."""
+        return BasePointTable(self, point, in_form)
+
+    def is_on_curve_batch(self, pts, in_form=AFFINE):
+        """flags[i] = pts[i].is_on_curve() (src/curve/affine.rs:364-368, projective.rs:940-946, jacobian.rs:930-938)"""
+        wi = self._out_width(in_form)
+        if _is_torch(pts):
+            p = self._dev(pts, 8, wi)
+            flags = self._empty((p.shape[0],), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_is_on_curve_batch_dev(self._h, p.data_ptr(), in_form, flags.data_ptr(), p.shape[0]))
+            return flags
+        p = self._np(pts, np.uint64, wi)
+        flags = np.empty(len(p), np.uint8)
+        self._check(self._lib.cheetah_is_on_curve_batch(self._h, p.ctypes.data, in_form, flags.ctypes.data, len(p)))
+        return flags
 
     # -- multi-scalar ladders, subgroup check, cofactor clearing ----------------------
     def _many(self, fname, pts, scalars, m, ns, in_form, out_form):
@@ -420,6 +461,53 @@ class Engine:
         v = C.c_float()
         self._check(self._lib.cheetah_timer_stop_ms(self._h, C.byref(v)))
         return v.value
+
+
+class BasePointTable:
+    """BasePointTable for a caller-supplied base (src/lookup.rs:136-234): `create` at construction,
+    `multiply_batch` = BasePointTable::multiply over a batch of scalars."""
+
+    def __init__(self, engine, point, in_form=AFFINE):
+        self._eng = engine
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1)
+        if pt.size != (12 if in_form == AFFINE else 18):
+            raise ValueError("one point: 12 limbs (AFFINE) or 18 (PROJECTIVE)")
+        h = C.c_void_p()
+        engine._check(engine._lib.cheetah_basepoint_table_create(engine._h, pt.ctypes.data, in_form, C.byref(h)))
+        self._t = h
+
+    def close(self):
+        if getattr(self, "_t", None) and getattr(self._eng, "_h", None):
+            self._eng._lib.cheetah_basepoint_table_destroy(self._t)
+        self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read(self):
+        """The 256 affine entries (32 x LookupTable<8>), table-major."""
+        out = np.empty((256, 12), np.uint64)
+        self._eng._check(self._eng._lib.cheetah_basepoint_table_read(self._eng._h, self._t, out.ctypes.data, 256))
+        return out
+
+    def multiply_batch(self, scalars, out_form=PROJECTIVE):
+        e = self._eng
+        w = e._out_width(out_form)
+        if _is_torch(scalars):
+            s = e._dev(scalars, 1, 32)
+            n = s.shape[0]
+            out, inf = e._empty((n, w), torch.uint64), e._empty((n,), torch.uint8)
+            e._use_torch_stream()
+            e._check(e._lib.cheetah_basepoint_table_multiply_batch_dev(e._h, self._t, s.data_ptr(), out.data_ptr(), inf.data_ptr(), n, out_form))
+            return out, inf
+        s = e._np(scalars, np.uint8, 32)
+        n = len(s)
+        out, inf = np.empty((n, w), np.uint64), np.empty(n, np.uint8)
+        e._check(e._lib.cheetah_basepoint_table_multiply_batch(e._h, self._t, s.ctypes.data, out.ctypes.data, inf.ctypes.data, n, out_form))
+        return out, inf
 
 
 # ---------------------------------------------------------------------------

@@ -45,12 +45,17 @@ struct JacobianPoint {
 };
 static_assert(sizeof(Fp6) == 48 && sizeof(AffinePoint) == 96 && sizeof(ProjectivePoint) == 144, "ABI layout");
 
-// One GPU.  Owns the device tables the reference builds with lazy_static
-// (BASEPOINT_TABLE, shift points; src/constants.rs:18-90).
+// One GPU or several.  Owns the device tables the reference builds with lazy_static
+// (BASEPOINT_TABLE, shift points; src/constants.rs:18-90), replicated per device; with several
+// devices every batch call is sharded contiguously over them and gathered into the caller's arrays.
 class Context {
 public:
     explicit Context(int device = 0) {
-        int rc = cheetah_ctx_create(device, &h_);
+        int rc = cheetah_ctx_create(&device, 1, &h_);
+        if (rc != 0) throw Error(rc, cheetah_last_error(nullptr));
+    }
+    explicit Context(const std::vector<int>& devices) {
+        int rc = cheetah_ctx_create(devices.data(), (int)devices.size(), &h_);
         if (rc != 0) throw Error(rc, cheetah_last_error(nullptr));
     }
     ~Context() {
@@ -134,6 +139,32 @@ struct BasePointTableT {
     }
 };
 static const BasePointTableT BASEPOINT_TABLE{};
+
+// BasePointTable::create(&P) for a caller-supplied base, src/lookup.rs:164-173; multiply, :189-206
+class BasePointTable {
+public:
+    BasePointTable(const Context& ctx, const ProjectivePoint& p) : ctx_(ctx) {
+        ctx.check(cheetah_basepoint_table_create(ctx.get(), u64p(&p), CHEETAH_PROJECTIVE, &t_));
+    }
+    BasePointTable(const Context& ctx, const AffinePoint& p) : ctx_(ctx) {
+        ctx.check(cheetah_basepoint_table_create(ctx.get(), u64p(&p), CHEETAH_AFFINE, &t_));
+    }
+    ~BasePointTable() {
+        if (t_) cheetah_basepoint_table_destroy(t_);
+    }
+    BasePointTable(const BasePointTable&) = delete;
+    BasePointTable& operator=(const BasePointTable&) = delete;
+    std::vector<ProjectivePoint> multiply_batch(const std::vector<Scalar>& by) const {
+        std::vector<ProjectivePoint> out(by.size());
+        ctx_.check(cheetah_basepoint_table_multiply_batch(ctx_.get(), t_, by.data()->bytes.data(), u64p(out.data()), nullptr, by.size(),
+                                                          CHEETAH_PROJECTIVE));
+        return out;
+    }
+
+private:
+    const Context& ctx_;
+    cheetah_basepoint_table* t_ = nullptr;
+};
 
 // ProjectivePoint::multiply(&self, by), src/curve/projective.rs:614-625 (constant time)
 inline std::vector<ProjectivePoint> multiply_batch(const Context& ctx, const std::vector<ProjectivePoint>& p,

@@ -19,10 +19,13 @@
  *    always canonical (each limb < p).
  *  - every call returns 0 on success or a negative cheetah_status; nothing
  *    aborts or throws across the boundary; cheetah_last_error() has the text.
- *  - a context belongs to ONE device and one host thread at a time; calls are
- *    issued on the context's stream.  `_dev` entry points take DEVICE pointers
- *    (8-byte aligned; Fp6 arrays 16-byte aligned) and are asynchronous on that stream; the others take HOST
- *    pointers, copy, run the same kernels and return after the results are back.
+ *  - a context belongs to one host thread at a time and to one device or several (cheetah_ctx_create);
+ *    calls are issued on the context's stream.  `_dev` entry points take DEVICE pointers (memory of the
+ *    context's first device; 8-byte aligned, Fp6 arrays 16-byte aligned) and are asynchronous on that stream;
+ *    the others take HOST pointers and return after the results are back: per device a pipeline of chunks
+ *    (upload / kernels / download overlapped, staging buffers kept in the context: no allocation per call).
+ *  - with several devices every call shards [0, n) into contiguous ranges, one per device, runs them
+ *    concurrently and gathers the results into the caller's arrays (host arrays, or the first device's).
  *  - the caller owns all buffers; the library keeps no pointer after return.
  */
 #ifndef CHEETAH_HIP_H
@@ -53,8 +56,12 @@ typedef enum { CHEETAH_AFFINE = 0, CHEETAH_PROJECTIVE = 1, CHEETAH_JACOBIAN = 2 
  * first use: BASEPOINT_TABLE (src/constants.rs:21-22, src/lookup.rs:164-173),
  * BASEPOINT_LOOKUP (src/constants.rs:26-27), the shift point and the
  * MINUS_SHIFT_POINT_ARRAY entries the ladders use (src/constants.rs:43-90). */
-int32_t cheetah_ctx_create(int device_id, cheetah_ctx **out);
+/* device_ids[0 .. n_dev): the HIP devices the context runs on (1 <= n_dev <= 64, no device twice, every id
+ * below hipGetDeviceCount; anything else is CHEETAH_ERR_INVALID, no visible device CHEETAH_ERR_NO_DEVICE).  The
+ * tables are replicated on every device.  n_dev = 1 is the plain single-GPU context. */
+int32_t cheetah_ctx_create(const int *device_ids, int n_dev, cheetah_ctx **out);
 int32_t cheetah_ctx_destroy(cheetah_ctx *ctx);
+int32_t cheetah_ctx_num_devices(const cheetah_ctx *ctx);
 /* Issue all following work on an existing hipStream_t (e.g. torch's current stream).
  * NULL is HIP's default (null) stream, as everywhere in HIP.  A new context starts on a
  * private non-blocking stream; cheetah_ctx_use_own_stream() goes back to it. */
@@ -108,23 +115,55 @@ int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx *ctx, const uint64_t *x
  * out_form = CHEETAH_JACOBIAN  : &BASEPOINT_LOOKUP * &Scalar (src/constants.rs:102-135): radix-256
  *                                digits, LookupTable<128>, modified-Jacobian accumulator; out = 18
  *                                limbs = the reference's Jacobian (X, Y, Z); inf as for PROJECTIVE
- * BASEPOINT_TABLE: scalars whose top nibble exceeds 7 are outside LookupTable<8>'s range in the
- * reference: the call fails with CHEETAH_ERR_SCALAR (host entry point) or leaves
- * inf[i] = 0xFF for that element (device entry point).  BASEPOINT_LOOKUP takes any 32 bytes. */
+ * BASEPOINT_TABLE (AFFINE and PROJECTIVE alike): scalars whose top nibble exceeds 7 are outside LookupTable<8>'s
+ * range in the reference (a debug_assert there).  The host entry point fails with CHEETAH_ERR_SCALAR
+ * before anything runs; the device entry point, which cannot look at the scalars, rejects the ELEMENT: its limbs are
+ * written as zeros and inf[i] = 0xFF, the same for both forms -- so inf must not be NULL for these two forms.
+ * BASEPOINT_LOOKUP (JACOBIAN) takes any 32 bytes, and its inf may be NULL. */
 int32_t cheetah_mul_by_generator_batch(cheetah_ctx *ctx, const uint8_t *scalars32, uint64_t *out, uint8_t *inf,
                                        size_t n, int out_form);
 int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx *ctx, const uint8_t *scalars32, uint64_t *out, uint8_t *inf,
                                            size_t n, int out_form);
 
+/* ---- fixed base, caller-supplied point ---------------------------------------
+ * cheetah_basepoint_table_create   BasePointTable::create(&P) / BasePointTable::from(P)    src/lookup.rs:138-173
+ *                                  point: HOST pointer to ONE point, in_form AFFINE (12 limbs; (0, 1) is the identity)
+ *                                  or PROJECTIVE (18 limbs).  Builds on every device of the context the 32 x
+ *                                  LookupTable<8> of 256^i P (24 KiB) and the widened table of the AFFINE form.
+ * cheetah_basepoint_table_multiply_batch[_dev]
+ *                                  out[i] = scalars[i] * P = BasePointTable::multiply        src/lookup.rs:189-206
+ *                                  (multiply_vartime, :216-233, is the same body -- SURVEY Q2 -- hence the same call).
+ *                                  out_form PROJECTIVE: the reference's comb step for step, its own (X:Y:Z);
+ *                                  AFFINE: the affine point by the widened comb.  Range rule and inf as for
+ *                                  cheetah_mul_by_generator_batch.  With P = G this is `&BASEPOINT_TABLE * &Scalar`
+ *                                  (the relation the reference tests, src/curve/projective.rs:1328-1351).
+ * cheetah_basepoint_table_read     the 256 affine entries, table-major (tests; get_basepoint() is entry 0, :176-178)
+ * Like the reference's ladders the comb adds with the incomplete formulas from the shift point: a base chosen
+ * against the shift point (P = +-2^j S ...) is outside what either implementation promises. */
+typedef struct cheetah_basepoint_table cheetah_basepoint_table;
+int32_t cheetah_basepoint_table_create(cheetah_ctx *ctx, const uint64_t *point, int in_form, cheetah_basepoint_table **out);
+int32_t cheetah_basepoint_table_destroy(cheetah_basepoint_table *table);
+int32_t cheetah_basepoint_table_multiply_batch(cheetah_ctx *ctx, const cheetah_basepoint_table *table, const uint8_t *scalars32,
+                                               uint64_t *out, uint8_t *inf, size_t n, int out_form);
+int32_t cheetah_basepoint_table_multiply_batch_dev(cheetah_ctx *ctx, const cheetah_basepoint_table *table,
+                                                   const uint8_t *scalars32, uint64_t *out, uint8_t *inf, size_t n, int out_form);
+int32_t cheetah_basepoint_table_read(cheetah_ctx *ctx, const cheetah_basepoint_table *table, uint64_t *out_xy, size_t max_points);
+
 /* ---- variable base ---------------------------------------------------------
  * out[i] = scalars[i] * pts[i]
  * cheetah_multiply_batch          radix-16 signed windows, LookupTable<16>, constant-time table scan
  * cheetah_multiply_vartime_batch  width-5 NAF, NafLookupTable<8>, quirk Q1: always 256 doublings
- * The (in_form, out_form) pair names the reference method, as its own types do:
- *   PROJECTIVE on either side : ProjectivePoint::multiply / multiply_vartime  src/curve/projective.rs:614-662
- *   JACOBIAN on either side   : JacobianPoint::multiply / multiply_vartime    src/curve/jacobian.rs:599-649
- *   AFFINE -> AFFINE          : AffinePoint::multiply / multiply_vartime, which delegate to
- *                               JacobianPoint's (src/curve/affine.rs:373-386)
+ * The (in_form, out_form) pair names the reference method whose RESULT is returned, as its own types do:
+ *   out_form PROJECTIVE       : ProjectivePoint::multiply / multiply_vartime  src/curve/projective.rs:614-662,
+ *                               its own (X:Y:Z): the projective accumulator and, for vartime, its NAF sequence per lane
+ *   out_form JACOBIAN         : JacobianPoint::multiply / multiply_vartime    src/curve/jacobian.rs:599-649,
+ *                               its own (X, Y, Z): the modified-Jacobian accumulator, same schedules
+ *   out_form AFFINE           : the affine point of the method the in_form names (AffinePoint::multiply* delegate to
+ *                               JacobianPoint's, src/curve/affine.rs:373-386).  An affine point does not depend on the
+ *                               schedule that reached it, so the cheapest one runs: the modified-Jacobian accumulator
+ *                               also for PROJECTIVE inputs, and for multiply_vartime the fixed-window ladder with
+ *                               indexed (variable-time) table reads instead of the NAF ladder -- except for scalars
+ *                               with bit 255 set, where the two differ and the NAF ladder runs
  *   PROJECTIVE with JACOBIAN  : no such method in the reference; CHEETAH_ERR_INVALID
  * in_form : CHEETAH_AFFINE (12 limbs; (0, 1) is read as the identity), CHEETAH_PROJECTIVE or
  *           CHEETAH_JACOBIAN (18 limbs).
@@ -195,6 +234,13 @@ int32_t cheetah_is_torsion_free_batch_dev(cheetah_ctx *ctx, const uint64_t *pts,
 int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint64_t *out, uint8_t *inf,
                                          size_t n, int out_form);
 
+/* ---- curve membership ------------------------------------------------------------
+ * flags[i] = is_on_curve(pts[i]):  AffinePoint     src/curve/affine.rs:364-368  (y^2 - x (x^2 + 1) == B, or the identity (0, 1))
+ *                                  ProjectivePoint src/curve/projective.rs:940-946 (Y^2 Z == X^3 + X Z^2 + B Z^3, or Z == 0)
+ *                                  JacobianPoint   src/curve/jacobian.rs:930-938   (Y^2 == X^3 + X Z^4 + B Z^6, or Z == 0) */
+int32_t cheetah_is_on_curve_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint8_t *flags, size_t n);
+int32_t cheetah_is_on_curve_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint8_t *flags, size_t n);
+
 /* ---- point encodings (src/curve/encoding.rs) ------------------------------------
  * cheetah_encode_uncompressed_batch  AffinePoint::to_uncompressed = UncompressedPoint::from_affine   :169-183
  *                                    97 bytes: x | y canonical little-endian (zeros for the identity), flag byte bit 7 = infinity
@@ -250,6 +296,9 @@ typedef enum {
     CHEETAH_OP_MJAC_DOUBLE, CHEETAH_OP_MJAC_ADD_MIXED_UNCHECKED
 } cheetah_debug_op;
 int32_t cheetah_debug_op_dev(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* A multi-shard context whose n_shards shards all live on ONE device: the sharding, peer-copy and gather paths of a
+ * multi-device context on a one-GPU box (tests only; cheetah_ctx_create itself rejects a device listed twice). */
+int32_t cheetah_debug_ctx_create_replicated(int device_id, int n_shards, cheetah_ctx **out);
 /* Measured v_mad_u64_u32 issue rate of this device in 1e12 lane-ops/s (roofline denominator). */
 int32_t cheetah_calibrate_mad_peak(cheetah_ctx *ctx, double *tera_mads_per_s);
 /* How many scalar multiplications one kernel launch of cheetah_multiply_batch_dev (vartime = 0) or

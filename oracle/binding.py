@@ -101,6 +101,9 @@ def lib():
         "ora_jac_multiply": (None, [u64p, u8p, u64p]),
         "ora_jac_multiply_vartime": (None, [u64p, u8p, u64p]),
         "ora_num_threads": (C.c_int, []),
+        "ora_basepoint_table_create": (None, [u64p, C.c_int, u64p, u8p]),
+        "ora_basepoint_table_multiply_batch": (None, [u64p, u8p, u8p, u64p, u8p, C.c_size_t, C.c_int]),
+        "ora_affine_is_on_curve": (C.c_int, [u64p]),
         "ora_fp6_mul_batch": (None, [u64p, u64p, u64p, C.c_size_t]),
         "ora_fp6_square_batch": (None, [u64p, u64p, C.c_size_t]),
         "ora_fp6_invert_batch": (None, [u64p, u64p, u8p, C.c_size_t]),
@@ -274,3 +277,29 @@ def batch_normalize(p, jacobian, chunk=0):
     f = lib().ora_jac_batch_normalize_chunked if jacobian else lib().ora_proj_batch_normalize_chunked
     f(p, n, chunk, xy, inf)
     return xy, inf
+
+
+def basepoint_table_create(point, in_form=0):
+    """BasePointTable::create(&P): (256 x 12 limbs, 256 identity flags), src/lookup.rs:164-173."""
+    p = _u64(point).reshape(-1)
+    xy = np.empty((256, 12), np.uint64)
+    inf = np.empty(256, np.uint8)
+    lib().ora_basepoint_table_create(p, in_form, xy, inf)
+    return xy, inf
+
+
+def basepoint_table_multiply_batch(table, scalars, out_form=1):
+    """BasePointTable::multiply with a caller's table, src/lookup.rs:189-206."""
+    txy, tinf = table
+    s = _u8(scalars)
+    n = len(s)
+    out, inf = _out_bufs(n, out_form)
+    lib().ora_basepoint_table_multiply_batch(_u64(txy), _u8(tinf), s,
+                                             out, inf, n, out_form)
+    return out, inf
+
+
+def is_on_curve_batch(pts, in_form):
+    p = _u64(pts)
+    f = {0: lib().ora_affine_is_on_curve, 1: lib().ora_proj_is_on_curve, 2: lib().ora_jac_is_on_curve}[in_form]
+    return np.array([f(p[i]) for i in range(len(p))], np.uint8)

@@ -1307,6 +1307,41 @@ void ora_mul_by_generator_batch(const uint8_t *scalars, u64 *out, uint8_t *out_i
             emit_point(basepoint_table_multiply(scalars + 32 * i), 0, out, out_inf, i, out_form);
     }
 }
+/* BasePointTable::create(&P) for any base (src/lookup.rs:164-173): 32 x LookupTable<8> of 256^i P, flat, table-major */
+void ora_basepoint_table_create(const u64 *p_in, int in_form, u64 *out_xy, uint8_t *out_inf) {
+    proj point = load_in_point(p_in, in_form, 0);
+    affine t[8];
+    for (int i = 0; i < 32; i++) {
+        if (i > 0)
+            for (int k = 0; k < 8; k++) point = proj_double(point); /* double_multi(8) */
+        lookup_table_from_proj(point, 8, t);
+        for (int j = 0; j < 8; j++) affine_store(out_xy + 12 * (8 * i + j), out_inf + 8 * i + j, t[j]);
+    }
+}
+/* BasePointTable::multiply with a caller's table (src/lookup.rs:189-206), over a batch */
+void ora_basepoint_table_multiply_batch(const u64 *table_xy, const uint8_t *table_inf, const uint8_t *scalars, u64 *out,
+                                        uint8_t *out_inf, size_t n, int out_form) {
+    ora_init();
+    affine tab[32][8];
+    for (int i = 0; i < 256; i++) tab[i / 8][i % 8] = affine_load(table_xy + 12 * i, table_inf[i]);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        int8_t a[64];
+        ora_bytes_to_radix_16(scalars + 32 * i, a);
+        proj acc = proj_from_affine(SHIFT_POINT);
+        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lookup_get_point(tab[j / 2], 8, a[j]));
+        for (int k = 0; k < 4; k++) acc = proj_double_unchecked(acc);
+        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lookup_get_point(tab[j / 2], 8, a[j]));
+        emit_point(proj_add_mixed_unchecked(acc, G_MINUS_SHIFT[4]), 0, out, out_inf, i, out_form);
+    }
+}
+/* AffinePoint::is_on_curve, src/curve/affine.rs:364-368; (0, 1) is the identity's encoding at the ABI */
+int ora_affine_is_on_curve(const u64 *xy) {
+    affine a = affine_load(xy, 0);
+    if (fp6_is_zero(a.x) && fp6_eq(a.y, FP6_ONE)) return 1;
+    fp6 lhs = fp6_sub(fp6_square(a.y), fp6_mul(a.x, fp6_add(fp6_square(a.x), FP6_ONE)));
+    return fp6_eq(lhs, CURVE_B);
+}
 void ora_multiply_batch(const u64 *pts, int in_form, const uint8_t *scalars, u64 *out, uint8_t *out_inf, size_t n,
                         int out_form) {
     ora_init();

@@ -119,6 +119,11 @@ void ora_jac_multiply_vartime(const uint64_t *p, const uint8_t *by32, uint64_t *
  * JacobianPoint::multiply* (what AffinePoint::multiply* delegates to);
  * ora_mul_by_generator_batch runs BASEPOINT_TABLE for forms 0 / 1 and
  * BASEPOINT_LOOKUP for form 2. ---- */
+/* BasePointTable for a caller-supplied base: create (src/lookup.rs:164-173) and multiply (:189-206) */
+void ora_basepoint_table_create(const uint64_t *p_in, int in_form, uint64_t *out_xy, uint8_t *out_inf); /* 256 x 12 limbs, 256 flags */
+void ora_basepoint_table_multiply_batch(const uint64_t *table_xy, const uint8_t *table_inf, const uint8_t *scalars, uint64_t *out,
+                                        uint8_t *out_inf, size_t n, int out_form);
+int ora_affine_is_on_curve(const uint64_t *xy); /* src/curve/affine.rs:364-368 */
 int ora_num_threads(void);
 void ora_fp6_mul_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 void ora_fp6_square_batch(const uint64_t *a, uint64_t *out, size_t n);

@@ -40,7 +40,7 @@ def test_no_gpu_means_error_not_fallback():
         pytest.skip("GPU present")
     lib = _capi.load()
     h = C.c_void_p()
-    rc = lib.cheetah_ctx_create(0, C.byref(h))
+    rc = lib.cheetah_ctx_create((C.c_int * 1)(0), 1, C.byref(h))
     assert rc in (_capi.ERR_NO_DEVICE, _capi.ERR_HIP) and not h.value
     assert lib.cheetah_last_error(None)
     from cheetah_amd import CheetahError, Engine

@@ -1,0 +1,309 @@
+"""GPU tests of the boundary itself (include/cheetah_hip.h), through the C ABI:
+  * the multi-device context: creation contract, error paths, and -- on this
+    one-GPU box -- its sharding / peer-copy / gather paths with all shards on one device
+    (cheetah_debug_ctx_create_replicated), every result equal to the single-device one;
+  * the host-pointer pipeline: batches of several chunks equal the `_dev` results;
+  * BasePointTable::create(P) / multiply for caller-supplied bases against the oracle (L1 + L2),
+    and the reference's own relation BasePointTable::create(g).multiply == g * s
+    (src/curve/projective.rs:1328-1351);
+  * the out-of-range rule of the BASEPOINT_TABLE forms; is_on_curve for the three point types.
+Bar: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cheetah_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+AFFINE, PROJECTIVE, JACOBIAN = 0, 1, 2
+P = 0xFFFFFFFF00000001
+IDENT = np.array([0] * 6 + [1] + [0] * 5, np.uint64)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cheetah_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng3():
+    """Three shards, all on device 0."""
+    from cheetah_amd import Engine
+    e = Engine(0, replicate=3)
+    yield e
+    e.close()
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint64:
+        return torch.from_numpy(a.view(np.int64)).cuda().view(torch.uint64)
+    return torch.from_numpy(a).cuda()
+
+
+def host(t):
+    import torch
+    if t.dtype == torch.uint64:
+        return t.view(torch.int64).cpu().numpy().view(np.uint64)
+    return t.cpu().numpy()
+
+
+def points(eng, seed, n):
+    """n affine points r_i G (host arrays), a few identities mixed in."""
+    xy, inf = eng.mul_by_generator_batch(synth.scalars(seed, n, 1 << 22), AFFINE)
+    xy = xy.copy()
+    for i in range(3, n, 97):
+        xy[i] = IDENT
+    return xy
+
+
+# ---------------------------------------------------------------- context -----
+
+def test_ctx_create_contract():
+    import torch
+    lib = _capi.load()
+    ndev = torch.cuda.device_count()
+    h = C.c_void_p()
+
+    def create(ids):
+        return lib.cheetah_ctx_create((C.c_int * max(1, len(ids)))(*ids), len(ids), C.byref(h))
+
+    assert create([]) == _capi.ERR_INVALID and not h.value
+    assert lib.cheetah_ctx_create(None, 1, C.byref(h)) == _capi.ERR_INVALID
+    assert lib.cheetah_ctx_create((C.c_int * 1)(0), 1, None) == _capi.ERR_INVALID
+    assert create([ndev]) == _capi.ERR_INVALID and b"out of range" in lib.cheetah_last_error(None)
+    assert create([-1]) == _capi.ERR_INVALID
+    assert create([0, 0]) == _capi.ERR_INVALID and b"twice" in lib.cheetah_last_error(None)
+    assert create([0, ndev]) == _capi.ERR_INVALID and not h.value
+    assert create([0]) == 0 and h.value
+    assert lib.cheetah_ctx_num_devices(h) == 1
+    # one context, one device: a product against the oracle-checked KAT (Fp6 mul, src/fp6.rs:1602-1627)
+    a = np.array([[7311251207099623982, 11101156575191577169, 3471450285948349450, 18081717484378824777,
+                   17271827452459074620, 13245881484175979175]], np.uint64)
+    b = np.array([[10376570592177434053, 2266730037751779421, 17604547680137376634, 8522386576290610241,
+                   4622828580943454349, 3310945140500303981]], np.uint64)
+    c = np.array([[16699204345089849089, 12290068205868725576, 15503892176250492698, 16153850030910369456,
+                   4357822170351527454, 15609745236686299732]], np.uint64)
+    out = np.zeros_like(a)
+    assert lib.cheetah_fp6_mul_batch(h, a.ctypes.data, b.ctypes.data, out.ctypes.data, 1) == 0
+    assert (out == c).all()
+    assert lib.cheetah_ctx_destroy(h) == 0
+    if ndev >= 2:  # a real two-device context where the box has one
+        assert create([0, 1]) == 0 and lib.cheetah_ctx_num_devices(h) == 2
+        out[:] = 0
+        assert lib.cheetah_fp6_mul_batch(h, a.ctypes.data, b.ctypes.data, out.ctypes.data, 1) == 0 and (out == c).all()
+        assert lib.cheetah_ctx_destroy(h) == 0
+    assert lib.cheetah_debug_ctx_create_replicated(0, 0, C.byref(h)) == _capi.ERR_INVALID
+
+
+@pytest.mark.parametrize("n", [1, 5, 256, 777, 3000])
+def test_sharded_context_equals_single_device_host_arrays(eng, eng3, n):
+    """Every host-pointer entry point on a 3-shard context == the single-device context (ragged n: the last
+    shard is short or empty)."""
+    assert eng3.num_devices == 3
+    a, b = synth.fp6_elements(11, n), synth.fp6_elements(12, n)
+    a[0] = 0
+    assert (eng3.fp6_mul_batch(a, b) == eng.fp6_mul_batch(a, b)).all()
+    assert (eng3.fp6_square_batch(a) == eng.fp6_square_batch(a)).all()
+    for f in ("fp6_invert_batch", "fp6_sqrt_batch"):
+        o3, s3 = getattr(eng3, f)(a)
+        o1, s1 = getattr(eng, f)(a)
+        assert (o3 == o1).all() and (s3 == s1).all()
+    k = synth.scalars(13, n)
+    pts = points(eng, 14, n)
+    for form in (AFFINE, PROJECTIVE, JACOBIAN):
+        g3, i3 = eng3.mul_by_generator_batch(k, form)
+        g1, i1 = eng.mul_by_generator_batch(k, form)
+        assert (g3 == g1).all() and (i3 == i1).all()
+    for in_form, out_form in ((AFFINE, AFFINE), (AFFINE, PROJECTIVE), (AFFINE, JACOBIAN)):
+        for vt in (False, True):
+            f3 = eng3.multiply_vartime_batch if vt else eng3.multiply_batch
+            f1 = eng.multiply_vartime_batch if vt else eng.multiply_batch
+            r3, j3 = f3(pts, k, in_form, out_form)
+            r1, j1 = f1(pts, k, in_form, out_form)
+            assert (r3 == r1).all() and (j3 == j1).all(), (in_form, out_form, vt)
+    jac, _ = eng.multiply_batch(pts, k, AFFINE, JACOBIAN)
+    x3, y3 = eng3.batch_normalize(jac, JACOBIAN), eng.batch_normalize(jac, JACOBIAN)
+    assert (x3[0] == y3[0]).all() and (x3[1] == y3[1]).all()
+    xy, inf = y3
+    for rec, enc in ((97, "to_uncompressed_batch"), (49, "to_compressed_batch")):
+        e3, e1 = getattr(eng3, enc)(xy, inf), getattr(eng, enc)(xy, inf)
+        assert (e3 == e1).all()
+        dec = eng3.from_uncompressed_batch if rec == 97 else eng3.from_compressed_batch
+        dxy, dinf, dsome = dec(e1, True)
+        assert (dxy == xy).all() and (dinf == inf).all() and dsome.all()
+    assert (eng3.is_torsion_free_batch(pts, AFFINE) == 1).all()
+    if n >= 2 and n % 2 == 0:
+        m3, mi3 = eng3.multiply_many_batch(pts, k, 2, AFFINE, AFFINE)
+        m1, mi1 = eng.multiply_many_batch(pts, k, 2, AFFINE, AFFINE)
+        assert (m3 == m1).all() and (mi3 == mi1).all()
+
+
+@pytest.mark.parametrize("n", [3, 1000, 2049])
+def test_sharded_context_equals_single_device_device_arrays(eng, eng3, n):
+    """The `_dev` entry points of a multi-shard context: slices travel to the other shards by peer copies and the
+    results come back into the caller's device arrays, asynchronously on the caller's stream."""
+    import torch
+    a, b = dev(synth.fp6_elements(21, n)), dev(synth.fp6_elements(22, n))
+    assert torch.equal(eng3.fp6_mul_batch(a, b).view(torch.int64), eng.fp6_mul_batch(a, b).view(torch.int64))
+    k = dev(synth.scalars(23, n))
+    pts = dev(points(eng, 24, n))
+    for form in (AFFINE, PROJECTIVE, JACOBIAN):
+        g3, i3 = eng3.mul_by_generator_batch(k, form)
+        g1, i1 = eng.mul_by_generator_batch(k, form)
+        assert torch.equal(g3.view(torch.int64), g1.view(torch.int64)) and torch.equal(i3, i1)
+    for out_form in (AFFINE, PROJECTIVE, JACOBIAN):
+        r3, j3 = eng3.multiply_batch(pts, k, AFFINE, out_form)
+        r1, j1 = eng.multiply_batch(pts, k, AFFINE, out_form)
+        assert torch.equal(r3.view(torch.int64), r1.view(torch.int64)) and torch.equal(j3, j1)
+    r3, j3 = eng3.multiply_vartime_batch(pts, k, AFFINE, PROJECTIVE)
+    x3, y3 = eng3.batch_normalize(r3, PROJECTIVE), eng.batch_normalize(r3, PROJECTIVE)
+    assert torch.equal(x3[0].view(torch.int64), y3[0].view(torch.int64)) and torch.equal(x3[1], y3[1])
+    e3, e1 = eng3.to_uncompressed_batch(*y3), eng.to_uncompressed_batch(*y3)
+    assert torch.equal(e3, e1)
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------- host-pointer pipeline -----
+
+def test_host_pipeline_many_chunks_equals_device_path(eng):
+    """Batches of several pipeline chunks (2^20 units for the elementwise kernels, 2^18 for the ladders) with a
+    ragged tail, through the host-pointer entry points, against the `_dev` entry points on the same data."""
+    n = (1 << 21) + 1234
+    a, b = synth.fp6_elements(31, n), synth.fp6_elements(32, n)
+    got = eng.fp6_mul_batch(a, b)
+    want = host(eng.fp6_mul_batch(dev(a), dev(b)))
+    assert (got == want).all()
+    m = 3 * (1 << 18) + 77
+    k = host(eng.synth_scalars(33, m))
+    pts_d, _ = eng.mul_by_generator_batch(eng.synth_scalars(34, m), AFFINE)
+    pts = host(pts_d)
+    got, ginf = eng.multiply_batch(pts, k, AFFINE, AFFINE)
+    want, winf = eng.multiply_batch(pts_d, dev(k), AFFINE, AFFINE)
+    assert (got == host(want)).all() and (ginf == host(winf)).all()
+    # a second, smaller call re-uses the staging buffers
+    got2, _ = eng.multiply_batch(pts[:1000], k[:1000], AFFINE, AFFINE)
+    assert (got2 == got[:1000]).all()
+    nxy, ninf = eng.batch_normalize(host(eng.multiply_batch(pts_d[:5000], dev(k[:5000]), AFFINE, JACOBIAN)[0]), JACOBIAN)
+    assert (nxy == got[:5000]).all()
+
+
+# ------------------------------------------------------------ BasePointTable -----
+
+def test_basepoint_table_create_and_multiply_random_bases(eng, ora):
+    rng = np.random.default_rng(41)
+    bases = host(eng.mul_by_generator_batch(dev(synth.scalars(41, 3)), AFFINE)[0])
+    proj_base = host(eng.multiply_batch(dev(bases[:1]), dev(synth.scalars(42, 1)), AFFINE, PROJECTIVE)[0])[0]  # Z != 1
+    n = 300
+    k = synth.scalars(43, n).copy()
+    k[0] = 0
+    k[1] = 0
+    k[1, 0] = 1
+    k[2] = np.frombuffer(((1 << 255) - 1).to_bytes(32, "little"), np.uint8)
+    k[3] = np.frombuffer((synth.Q - 1).to_bytes(32, "little"), np.uint8)
+    for base, form in [(bases[0], AFFINE), (bases[1], AFFINE), (proj_base, PROJECTIVE), (IDENT, AFFINE)]:
+        t = eng.basepoint_table(base, form)
+        wt = ora.basepoint_table_create(base, form)
+        assert (t.read() == wt[0]).all()
+        assert ((t.read()[:, :6] == 0).all(axis=1) == (wt[1] == 1)).all()   # identities are stored as (0, 1)
+        for out_form in (PROJECTIVE, AFFINE):
+            want, winf = ora.basepoint_table_multiply_batch(wt, k, out_form)
+            got, ginf = t.multiply_batch(k, out_form)                      # host arrays
+            assert (got == want).all() and (ginf == winf).all(), (form, out_form)
+            gd, gi = t.multiply_batch(dev(k), out_form)                    # device arrays
+            assert (host(gd) == want).all() and (host(gi) == winf).all()
+        t.close()
+
+
+def test_basepoint_table_of_generator_is_basepoint_table(eng):
+    """BasePointTable::create(g).multiply(s) == BASEPOINT_TABLE.multiply(s) == g.multiply(s) for random s -- the
+    reference's cross-path test (src/curve/projective.rs:1328-1351), projective representative included."""
+    g = eng.read_table(0)[0]
+    t = eng.basepoint_table(g, AFFINE)
+    assert (t.read() == eng.read_table(0)).all()
+    k = dev(synth.scalars(44, 4096))
+    for form in (PROJECTIVE, AFFINE):
+        a, ai = t.multiply_batch(k, form)
+        b, bi = eng.mul_by_generator_batch(k, form)
+        assert (host(a) == host(b)).all() and (host(ai) == host(bi)).all()
+    gg = dev(np.repeat(g[None, :], 4096, axis=0))
+    c, ci = eng.multiply_batch(gg, k, AFFINE, AFFINE)
+    assert (host(c) == host(a)).all()
+    t.close()
+
+
+def test_basepoint_table_on_sharded_context(eng, eng3):
+    base = host(eng.mul_by_generator_batch(dev(synth.scalars(45, 1)), AFFINE)[0])[0]
+    t1, t3 = eng.basepoint_table(base), eng3.basepoint_table(base)
+    k = synth.scalars(46, 1500)
+    for form in (PROJECTIVE, AFFINE):
+        a, ai = t1.multiply_batch(k, form)
+        b, bi = t3.multiply_batch(k, form)
+        c, ci = t3.multiply_batch(dev(k), form)
+        assert (a == b).all() and (ai == bi).all() and (host(c) == a).all()
+    t1.close()
+    t3.close()
+
+
+def test_out_of_range_scalars_are_rejected_the_same_in_both_forms(eng):
+    """BASEPOINT_TABLE forms and scalars with the top nibble > 7: the host entry point refuses the
+    call; the device entry point rejects the element -- zero limbs, inf = 0xFF -- whatever the output form, and
+    needs inf; the neighbours are untouched.  BASEPOINT_LOOKUP (JACOBIAN) takes any scalar."""
+    from cheetah_amd import CheetahError
+    k = synth.scalars(47, 600).copy()
+    bad = [0, 255, 256, 599]
+    for i in bad:
+        k[i, 31] |= 0x80
+    with pytest.raises(CheetahError) as e:
+        eng.mul_by_generator_batch(k, AFFINE)
+    assert e.value.code == _capi.ERR_SCALAR
+    good = k.copy()
+    good[:, 31] &= 0x7F
+    for form in (AFFINE, PROJECTIVE):
+        out, inf = eng.mul_by_generator_batch(dev(k), form)
+        ref, rinf = eng.mul_by_generator_batch(dev(good), form)
+        out, inf, ref, rinf = host(out), host(inf), host(ref), host(rinf)
+        mask = np.zeros(600, bool)
+        mask[bad] = True
+        assert (inf[mask] == 0xFF).all() and (out[mask] == 0).all()
+        assert (out[~mask] == ref[~mask]).all() and (inf[~mask] == rinf[~mask]).all()
+    lib = _capi.load()
+    kd = dev(k)
+    o = dev(np.zeros((600, 18), np.uint64))
+    assert lib.cheetah_mul_by_generator_batch_dev(eng._h, kd.data_ptr(), o.data_ptr(), None, 600, PROJECTIVE) == _capi.ERR_INVALID
+    assert lib.cheetah_mul_by_generator_batch_dev(eng._h, kd.data_ptr(), o.data_ptr(), None, 600, JACOBIAN) == 0
+    eng.synchronize()
+
+
+# --------------------------------------------------------------- is_on_curve -----
+
+def test_is_on_curve_all_forms(eng, ora):
+    n = 200
+    k = synth.scalars(51, n)
+    aff = points(eng, 52, n)
+    proj, _ = eng.multiply_batch(aff, k, AFFINE, PROJECTIVE)
+    jac, _ = eng.multiply_batch(aff, k, AFFINE, JACOBIAN)
+    for form, pts in ((AFFINE, aff.copy()), (PROJECTIVE, proj.copy()), (JACOBIAN, jac.copy())):
+        pts[5, 0] ^= 1                       # off the curve
+        pts[6, 7] = (int(pts[6, 7]) + 1) % P
+        pts[7, :6] = P                       # non-canonical zero x
+        want = ora.is_on_curve_batch(pts, form)
+        assert want[5] == 0 and want[6] == 0 and want.sum() >= n - 4
+        assert (eng.is_on_curve_batch(pts, form) == want).all()
+        assert (host(eng.is_on_curve_batch(dev(pts), form)) == want).all()
+    # the point of the curve that is not in the prime-order subgroup (src/curve/projective.rs:1407-1425) is on the curve
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as f:
+        kats = json.load(f)
+    v = kats["non_subgroup_point"]
+    pt = np.array([v["x"] + v["y"]], np.uint64)
+    assert eng.is_on_curve_batch(pt, AFFINE)[0] == 1 and eng.is_torsion_free_batch(pt, AFFINE)[0] == 0

@@ -814,8 +814,8 @@ def test_full_size_configs_2_3_properties(eng, ora):
 def test_full_size_config5_properties(eng, ora):
     """BASELINE config 5 at full size (2^26 seeded (P_i, k_i), bench.py's inputs), in four blocks of 2^24:
     constant-time == variable-time for ALL i (scan vs indexed lookups), a strided sample against the oracle,
-    no identities, and the wrap-around sum of all canonical limbs equals the checksum bench.py prints
-    (the latest profiles/r*_bench_2p26.json) -- a checksum of checksums over the blocks."""
+    no identities, and the wrap-around sum of all canonical limbs equals the committed golden checksum
+    (tests/golden/config5_checksum.json; bench.py prints the same figure) -- a checksum of checksums over the blocks."""
     import torch
     from cheetah_amd import AFFINE
     m, blocks = 1 << 24, 4
@@ -833,20 +833,17 @@ def test_full_size_config5_properties(eng, ora):
         wxy, winf = ora.multiply_batch(host(take(pts, idx)), 0, host(take(K, idx)), 0)
         assert (host(take(ct, idx)) == wxy).all() and not winf.any()
         del r, pts, K, ct, vt
-    import glob
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_2p26.json")))
-    assert lines, "no committed bench line to compare the checksum with"
-    with open(lines[-1]) as f:
+    with open(os.path.join(ROOT, "tests", "golden", "config5_checksum.json")) as f:
         assert "%016x" % total == json.load(f)["checksum"]
 
 
 def test_full_size_config4_batch_normalize(eng, ora):
-    """BASELINE config 4 at 2^22 (the 2^24 run is bench.py's): Jacobian points
-    (x l^2, y l^3, l) built on the device from k_i*G, normalised back, must equal
-    the affine points they came from, identities included."""
+    """BASELINE config 4 at its full size, 2^24 Jacobian points (2.25 GiB): (x l^2, y l^3, l) built on the
+    device from k_i*G, normalised back, must equal the affine points they came from, identities
+    included; the first 4 096 also against the oracle's JacobianPoint::batch_normalize."""
     import torch
     from cheetah_amd import AFFINE, JACOBIAN
-    n = 1 << 22
+    n = 1 << 24
     S = eng.synth_scalars(4, n)
     aff, _ = eng.mul_by_generator_batch(S, AFFINE)
     lam = eng.synth_fp6(4, n)

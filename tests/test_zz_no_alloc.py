@@ -33,7 +33,7 @@ def test_noalloc_entry_point_matches_the_allocating_one():
     assert torch.cuda.is_available()
     lib = _capi.load()
     h = C.c_void_p()
-    assert lib.cheetah_ctx_create(0, C.byref(h)) == 0, lib.cheetah_last_error(None)
+    assert lib.cheetah_ctx_create((C.c_int * 1)(0), 1, C.byref(h)) == 0, lib.cheetah_last_error(None)
     try:
         # inputs: P_i = r_i G (device), k_i seeded; edge cases: an identity input, scalars with the top nibble > 7
         # (16-entry tables), zero and one; 40 000 > 128 workgroups x 256 lanes, so the capped grid strides
