@@ -625,10 +625,10 @@ template <int JAC>
 static int32_t batch_normalize_impl(cheetah_ctx* ctx, const u64* xyz, u64* xy, u8* inf, size_t n) {
     SET_DEVICE(ctx);
     if (!aligned16(xyz) || !aligned16(xy)) return fail(ctx, CHEETAH_ERR_INVALID, "point arrays must be 16-byte aligned");
-    constexpr int CHUNK = 8;
+    constexpr int CHUNK = CH_BN_CHUNK;
     size_t nchunks = (n + CHUNK - 1) / CHUNK;
     int grid = lane_grid(ctx, nchunks, CH_BN_WAVES);
-    hipLaunchKernelGGL((k_batch_normalize<JAC, CHUNK>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
+    hipLaunchKernelGGL((k_batch_normalize<JAC, CHUNK, CH_BN_NLDS>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }

@@ -26,7 +26,7 @@ constexpr int BLOCK = 256;
 #define CH_MANY_WAVES 2
 #endif
 #ifndef CH_BN_WAVES
-#define CH_BN_WAVES 3
+#define CH_BN_WAVES 2
 #endif
 
 // ---------------------------------------------------------------------------
@@ -305,48 +305,94 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
 // tile + t, tile + BLOCK + t, ..., so at every step the workgroup touches BLOCK
 // consecutive 144-byte records with 16-byte accesses -- each 128-byte line is
 // fetched from HBM once -- instead of one record per 1 152 bytes.
-template <int JAC, int CHUNK>
+// Measured (MI355X, 2^24 Jacobian points, tools/bn_bench.py, profiles/r02_bn_variants.txt): what the kernel lacked was
+// not occupancy but loads in flight.  Every step's operands are now requested one step ahead of their use (the next
+// point's z in the forward pass; x, y, z of point j - 1 while point j is computed), which needs ~60 more VGPRs than
+// three waves per SIMD leave, so the kernel is compiled for two waves per SIMD: 8.0 G points/s against 7.35 before.
+// NLDS > 0 keeps the first NLDS prefix products of a chunk in LDS ([slot][limb][lane], 8-byte accesses, conflict
+// free) instead of registers; every (CHUNK, NLDS, waves) combination that does not spill measured 7.5 - 8.0 G/s
+// (chunk 4 - 12: the Fp6 inversion per chunk is not what bounds it), so the default is the simplest: 8, 0, 2.
+#ifndef CH_BN_CHUNK
+#define CH_BN_CHUNK 8
+#endif
+#ifndef CH_BN_NLDS
+#define CH_BN_NLDS 0
+#endif
+template <int JAC, int CHUNK, int NLDS>
 __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
                                                               u8* __restrict__ inf, size_t n) {
+    __shared__ u64 s_prefix[(NLDS > 0 ? NLDS : 1) * 6 * BLOCK];
+    const int t = threadIdx.x;
     const size_t tile_pts = (size_t)BLOCK * CHUNK;
     const size_t ntiles = (n + tile_pts - 1) / tile_pts;
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const size_t e0 = tile * tile_pts + threadIdx.x;
-        Fp6 prefix[CHUNK];  // prefix[j] = product of the lane's non-zero z's before its point j
+        const size_t e0 = tile * tile_pts + t;
+        Fp6 prefix[CHUNK > NLDS ? CHUNK - NLDS : 1];  // prefix[j - NLDS] = product of the lane's non-zero z's before its point j
         Fp6 acc = fp6_one();
+        Fp6 z_next = e0 < n ? load_fp6_vec(xyz + 18 * e0 + 12) : fp6_zero();
 #pragma unroll
         for (int j = 0; j < CHUNK; j++) {
-            const size_t e = e0 + (size_t)j * BLOCK;
-            prefix[j] = acc;
-            if (e < n) {
-                Fp6 z = load_fp6_vec(xyz + 18 * e + 12);
-                Fp6 m = fp6_mul(acc, z);
-                acc = fp6_select(m, acc, fp6_is_zero(z));
+            const Fp6 z = z_next;  // a point beyond n reads as z = 0: skipped like an identity, never stored
+            if (j + 1 < CHUNK) {
+                const size_t en = e0 + (size_t)(j + 1) * BLOCK;
+                z_next = en < n ? load_fp6_vec(xyz + 18 * en + 12) : fp6_zero();
             }
+            if (j < NLDS) {
+#pragma unroll
+                for (int l = 0; l < 6; l++) s_prefix[(j * 6 + l) * BLOCK + t] = acc.c[l];
+            } else {
+                prefix[j - NLDS] = acc;
+            }
+            Fp6 m = fp6_mul(acc, z);
+            acc = fp6_select(m, acc, fp6_is_zero(z));
         }
         bool some;
         acc = fp6_invert(acc, &some);
+        // backward pass, operands of point j - 1 requested while point j is computed
+        Fp6 nx, ny, nz;
+        {
+            const size_t e = e0 + (size_t)(CHUNK - 1) * BLOCK;
+            const bool in = e < n;
+            const u64* p = xyz + 18 * (in ? e : 0);
+            nx = load_fp6_vec(p);
+            ny = load_fp6_vec(p + 6);
+            nz = in ? load_fp6_vec(p + 12) : fp6_zero();
+        }
 #pragma unroll
         for (int j = CHUNK - 1; j >= 0; j--) {
             const size_t e = e0 + (size_t)j * BLOCK;
+            const Fp6 x = nx, y = ny, z = nz;
+            if (j > 0) {
+                const size_t ep = e - BLOCK;
+                const bool in = ep < n;
+                const u64* p = xyz + 18 * (in ? ep : 0);
+                nx = load_fp6_vec(p);
+                ny = load_fp6_vec(p + 6);
+                nz = in ? load_fp6_vec(p + 12) : fp6_zero();
+            }
+            Fp6 pre;
+            if (j < NLDS) {
+#pragma unroll
+                for (int l = 0; l < 6; l++) pre.c[l] = s_prefix[(j * 6 + l) * BLOCK + t];
+            } else {
+                pre = prefix[j - NLDS];
+            }
+            const bool skip = fp6_is_zero(z);
+            Fp6 zi = fp6_mul(pre, acc);  // 1 / z_j
+            Fp6 m = fp6_mul(acc, z);
+            acc = fp6_select(m, acc, skip);
+            Affine o;
+            if (JAC) {
+                Fp6 zi2 = fp6_square(zi);
+                o.x = fp6_mul(x, zi2);
+                o.y = fp6_mul(fp6_mul(y, zi2), zi);
+            } else {
+                o.x = fp6_mul(x, zi);
+                o.y = fp6_mul(y, zi);
+            }
+            o.inf = false;
+            if (skip) o = affine_identity();
             if (e < n) {
-                const u64* p = xyz + 18 * e;
-                Fp6 z = load_fp6_vec(p + 12);
-                const bool skip = fp6_is_zero(z);
-                Fp6 zi = fp6_mul(prefix[j], acc);  // 1 / z_j
-                Fp6 m = fp6_mul(acc, z);
-                acc = fp6_select(m, acc, skip);
-                Affine o;
-                if (JAC) {
-                    Fp6 zi2 = fp6_square(zi);
-                    o.x = fp6_mul(load_fp6_vec(p), zi2);
-                    o.y = fp6_mul(fp6_mul(load_fp6_vec(p + 6), zi2), zi);
-                } else {
-                    o.x = fp6_mul(load_fp6_vec(p), zi);
-                    o.y = fp6_mul(load_fp6_vec(p + 6), zi);
-                }
-                o.inf = false;
-                if (skip) o = affine_identity();
                 store_fp6_vec_canonical(xy + 12 * e, o.x);
                 store_fp6_vec_canonical(xy + 12 * e + 6, o.y);
                 inf[e] = o.inf ? 1 : 0;
