@@ -781,6 +781,86 @@ CH_DEV u32 build_table(const Proj& p, int n_entries, u64* s_tab, u64* s_z, u64* 
     return ident;
 }
 
+// The same table [P, 2P, ..., NP] (LookupTable<N>, N = 8 or 16) for an AFFINE P by affine doublings and additions
+// whose inversions are shared level by level (Montgomery's trick over the 1, 2, 4(, 8) operations of a level):
+//   level (lo, 2 lo]:  m even: m P = 2 (m/2 P);   m odd: m P = ((m - 1)/2) P + ((m + 1)/2) P
+// 2 M + 1..2 S per entry + 3 inversions (4 for N = 16) instead of N - 1 complete additions (12 M each) and a
+// normalisation -- the entries are affine points, so they do not depend on how they were reached.  Every exceptional
+// case (P the identity, or of order <= N: a doubling of a 2-torsion point, an addition of equal or opposite points)
+// makes a denominator zero, hence the level's product zero and its inversion `none`: the function then returns false
+// and the caller rebuilds that wave's tables with the reference's complete formulas (build_table).
+CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
+    bool bad = P.inf;
+    sc_store(s_tab, 0, 0, P.x, t, 12);
+    sc_store(s_tab, 0, 6, P.y, t, 12);
+    for (int lo = 1; lo < n_entries; lo *= 2) {
+        Fp6 acc = fp6_one();
+        for (int i = 0; i < lo; i++) {  // denominators d_i of entry m = lo + 1 + i, and their running products
+            const int m = lo + 1 + i;
+            Fp6 d;
+            if (m & 1)
+                d = fp6_sub(sc_load(s_tab, (m + 1) / 2 - 1, 0, t, 12), sc_load(s_tab, (m - 1) / 2 - 1, 0, t, 12));  // x_b - x_a
+            else
+                d = fp6_double(sc_load(s_tab, m / 2 - 1, 6, t, 12));  // 2 y
+            sc_store(s_z, i, 0, d, t, 6);
+            if (i == 0) {
+                acc = d;
+            } else {
+                sc_store(s_prefix, i, 0, acc, t, 6);
+                acc = fp6_mul(acc, d);
+            }
+        }
+        bool some;
+        acc = fp6_invert(acc, &some);
+        bad = bad || !some;
+        for (int i = lo - 1; i >= 0; i--) {
+            const int m = lo + 1 + i;
+            Fp6 inv = acc;  // 1 / d_i
+            if (i > 0) {
+                inv = fp6_mul(sc_load(s_prefix, i, 0, t, 6), acc);
+                acc = fp6_mul(acc, sc_load(s_z, i, 0, t, 6));
+            }
+            Fp6 x3, y3;
+            if (m & 1) {
+                const int a = (m - 1) / 2 - 1, b = (m + 1) / 2 - 1;
+                const Fp6 xa = sc_load(s_tab, a, 0, t, 12), ya = sc_load(s_tab, a, 6, t, 12);
+                const Fp6 lam = fp6_mul(fp6_sub(sc_load(s_tab, b, 6, t, 12), ya), inv);
+                x3 = fp6_sub(fp6_sub(fp6_square(lam), xa), sc_load(s_tab, b, 0, t, 12));
+                y3 = fp6_sub(fp6_mul(lam, fp6_sub(xa, x3)), ya);
+            } else {
+                const int h = m / 2 - 1;
+                const Fp6 xh = sc_load(s_tab, h, 0, t, 12);
+                Fp6 num = fp6_triple(fp6_square(xh));
+                num.c[0] = fp_add(num.c[0], 1ull);  // 3 x^2 + a, a = 1
+                const Fp6 lam = fp6_mul(num, inv);
+                x3 = fp6_sub(fp6_square(lam), fp6_double(xh));
+                y3 = fp6_sub(fp6_mul(lam, fp6_sub(xh, x3)), sc_load(s_tab, h, 6, t, 12));
+            }
+            sc_store(s_tab, m - 1, 0, x3, t, 12);
+            sc_store(s_tab, m - 1, 6, y3, t, 12);
+        }
+    }
+    return !bad;
+}
+
+// LookupTable<N>::from for the lane's input point: the shared-inversion affine construction, and for a wave that holds
+// an exceptional point the reference's own construction.  Returns the identity mask of the entries.
+template <int IN_FORM>
+CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
+    Affine pa;
+    if (IN_FORM == 1) {
+        pa = affine_from_proj(load_proj(pts + 18 * i));
+    } else {
+        const Proj p = load_input_point<IN_FORM>(pts, i);  // affine already (IN_FORM 2: normalised, as the reference does)
+        pa.x = p.x;
+        pa.y = p.y;
+        pa.inf = fp6_is_zero(p.z);
+    }
+    const bool ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t);
+    if (__any(!ok)) return build_table<false>(load_input_point<IN_FORM>(pts, i), n_entries, s_tab, s_z, s_prefix, t);
+    return 0u;
+}
+
 // Constant-time lookup (src/lookup.rs:81-102): read every entry, keep entry |d|.
 CH_DEV Affine scan_lookup(const u64* s_tab, int n_entries, u32 ident, int d, int t) {
     const int neg = d < 0;
@@ -861,8 +941,7 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
         const bool wide = (k[3] >> 60) > 7;
         if (DIRECT && __any((int)(k[3] >> 63))) continue;  // this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
-        const Proj p = load_input_point<IN_FORM>(pts, ii);
-        const u32 ident = build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_lookup_table<IN_FORM>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
         const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
@@ -982,8 +1061,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
         }
         const int n_entries = __any(wide) ? 16 : 8;
         for (int j = 0; j < m; j++) {
-            const Proj p = load_input_point<IN_FORM>(pts, gg * m + j);
-            s_ident[j * BLOCK + t] = build_table<false>(p, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
+            s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
         }
         ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S
         for (int w = 63; w >= 0; w--) {

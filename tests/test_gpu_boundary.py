@@ -307,3 +307,64 @@ def test_is_on_curve_all_forms(eng, ora):
     v = kats["non_subgroup_point"]
     pt = np.array([v["x"] + v["y"]], np.uint64)
     assert eng.is_on_curve_batch(pt, AFFINE)[0] == 1 and eng.is_torsion_free_batch(pt, AFFINE)[0] == 0
+
+
+# ------------------------------------------- low-order inputs (window-table fallback) -----
+
+def test_multiply_low_order_points_fall_back_to_the_complete_formulas(eng, ora, kats):
+    """The window table [P .. NP] is built by affine steps with shared inversions; a point of order <= N (or the
+    identity) makes a denominator zero and its wave rebuilds the table with the reference's complete additions.
+    Points of order 2, 5 and 10 exist on the curve (h = 2 * 5 * 29 * 181 * ...): T_d = (h / d) * (q * N) for the
+    reference's point N outside the prime-order subgroup (src/curve/projective.rs:1407-1425).  Mixed into ordinary
+    batches (first wave, a later wave), every ladder against the oracle, all forms."""
+    h = int.from_bytes(bytes(kats["cofactor_bytes"]), "little") if "cofactor_bytes" in kats else 0x2150b48e071ef610049bc3f5d54304e4a
+    v = kats["non_subgroup_point"]
+    N = np.array([v["x"] + v["y"]], np.uint64)
+
+    def sc(x):
+        return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).reshape(1, 32).copy()
+
+    # N itself has no 5-torsion component; random points of the curve (AffinePoint::from_x on seeded x) do, 4 times in 5
+    xy, xinf, some = ora.affine_from_x_batch(synth.fp6_elements(60, 24))
+    cand = np.concatenate([N, xy[(some == 1) & (xinf == 0)]])
+    q_cand, _ = ora.multiply_batch(cand, 0, np.repeat(sc(synth.Q), len(cand), axis=0), 0, vartime=True)
+    low = []
+    for d in (2, 5, 10):
+        T, tinf = ora.multiply_batch(q_cand, 0, np.repeat(sc(h // d), len(cand), axis=0), 0, vartime=True)
+        chk, cinf = ora.multiply_batch(T, 0, np.repeat(sc(d), len(cand), axis=0), 0, vartime=True)
+        assert (cinf == 1).all()                                   # d * T = O for every candidate
+        full = [i for i in range(len(cand)) if tinf[i] == 0 and all(
+            ora.multiply_batch(T[i:i + 1], 0, sc(e), 0, vartime=True)[1][0] == 0 for e in (1, 2, 5) if e < d and d % e == 0)]
+        assert full, d                                             # a point of order exactly d
+        low.append(T[full[0]])
+    assert (low[0][6:] == 0).all()                                 # order 2: y = 0
+    n = 320
+    pts = points(eng, 61, n)
+    for j, i in enumerate([0, 1, 2, 5, 200, 201, 202, 319]):
+        pts[i] = low[j % 3]
+    k = synth.scalars(62, n).copy()
+    k[1] = 0xFF                                                   # 16-entry table for the first wave
+    k[202, 31] |= 0xF0
+    for out_form in (AFFINE, JACOBIAN, PROJECTIVE):
+        for vt in (False, True):
+            want, winf = ora.multiply_batch(pts, 0, k, out_form, vartime=vt)
+            f = eng.multiply_vartime_batch if vt else eng.multiply_batch
+            got, ginf = f(dev(pts), dev(k), AFFINE, out_form)
+            assert (host(got) == want).all() and (host(ginf) == winf).all(), (out_form, vt)
+    want, winf = ora.multiply_many_batch(pts, 0, k, 2, 0)
+    got, ginf = eng.multiply_many_batch(dev(pts), dev(k), 2, AFFINE, AFFINE)
+    assert (host(got) == want).all() and (host(ginf) == winf).all()
+    # Jacobian and projective inputs of the same points: (x l^2, y l^3, l) and (x l, y l, l)
+    lam = synth.fp6_elements(63, n)
+    l2 = eng.fp6_square_batch(lam)
+    l3 = eng.fp6_mul_batch(l2, lam)
+    jac = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), l2), eng.fp6_mul_batch(pts[:, 6:].copy(), l3), lam], axis=1)
+    prj = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), lam), eng.fp6_mul_batch(pts[:, 6:].copy(), lam), lam], axis=1)
+    for i in range(3, n, 97):                                       # the identities of `points`
+        jac[i, 12:] = 0
+        prj[i, 12:] = 0
+    for arr, form in ((jac, JACOBIAN), (prj, PROJECTIVE)):
+        for out_form in (AFFINE, form):
+            want, winf = ora.multiply_batch(arr, form, k, out_form)
+            got, ginf = eng.multiply_batch(dev(arr), dev(k), form, out_form)
+            assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, out_form)
