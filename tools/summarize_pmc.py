@@ -26,7 +26,7 @@ if len(sys.argv) > 3:
     units = 1 << int(sys.argv[2])
     out = {"units_per_dispatch": units, "note": "FETCH_SIZE / WRITE_SIZE (KB) x 1024 / units; FETCH_SIZE as reported (8-byte-per-lane reads, uncalibrated width)"}
     for key, pat in (("k_multiply_ct", "k_multiply_ct<MJac, 0, 0, false>"), ("k_multiply_ct_direct", "k_multiply_ct<MJac, 0, 0, true>"),
-                     ("k_mul_by_generator", "k_mul_by_generator<0>")):
+                     ("k_mul_by_generator_wide", "k_mul_by_generator_wide<false>")):
         for k in rows:
             if k.startswith(pat) and "FETCH_SIZE" in rows[k] and "WRITE_SIZE" in rows[k]:
                 f = sum(rows[k]["FETCH_SIZE"]) / len(rows[k]["FETCH_SIZE"])
