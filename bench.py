@@ -61,8 +61,9 @@ def ceiling_model():
       Fp6 square = 21 x (4 + 4) + 6 x (1 + 13) + 5 x 9 + 5 doublings x 6 = 90 mad + 237 carry-class -> 269 (credited: 84)
       Fp6 add / sub / double = 36 carry-class -> 27
     Per window: 4 doublings (4 M + 4 S, the last without its z4 product; 8 linear operations each) + 1 mixed addition
-    (8 M + 5 S, 8 linear operations, the constant-time scan's 192 selects); 64 windows; the 8-entry table, the two
-    Fp6 inversions and the final normalisation ~ 55 k slots.  ceiling_frac = credited mad32 / those slots."""
+    (8 M + 5 S, 8 linear operations, the constant-time scan's 192 selects); 64 windows; the 8-entry table (26 M + 11 S
+    + 3 Fp6 inversions of ~3 600 slots each) and the final normalisation (an inversion + 4 M + S) ~ 36 k slots.
+    ceiling_frac = credited mad32 / those slots."""
     half = (3.70 - 2.11) / 2.11
     M = 150 + 267 * half
     S = 90 + 237 * half
@@ -70,7 +71,7 @@ def ceiling_model():
     dbl = 4 * M + 4 * S + 8 * L
     add = 8 * M + 5 * S + 8 * L + 192 * half
     window = 4 * dbl - M + add
-    slots = 64 * window + 55000
+    slots = 64 * window + 36000
     return {"min_mad_slots_per_unit": round(slots), "ceiling_frac": MAD32_PER_CT_MULT / slots}
 
 
@@ -292,7 +293,7 @@ def main():
             opts = dist.ProcessGroupNCCL.Options()
             opts.is_high_priority_stream = True
             dist.init_process_group("nccl", device_id=torch.device(device), pg_options=opts)
-        except (AttributeError, TypeError):
+        except (AttributeError, TypeError, ValueError):
             dist.init_process_group("nccl", device_id=torch.device(device))
 
     from cheetah_amd import AFFINE, Engine
