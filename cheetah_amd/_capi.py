@@ -27,6 +27,10 @@ SIGNATURES = {
     "cheetah_basepoint_table_multiply_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "cheetah_basepoint_table_read": (C.c_int32, [_vp, _vp, _vp, _sz]),
     "cheetah_is_on_curve_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_add_batch": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _sz]),
+    "cheetah_add_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _sz]),
+    "cheetah_double_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_double_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_is_on_curve_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_ctx_destroy": (C.c_int32, [_vp]),
     "cheetah_ctx_set_stream": (C.c_int32, [_vp, _vp]),

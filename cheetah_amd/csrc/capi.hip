@@ -1163,6 +1163,70 @@ extern "C" int32_t cheetah_is_on_curve_batch(cheetah_ctx* ctx, const uint64_t* p
     return is_on_curve_op(ctx, true, pts, in_form, flags, n);
 }
 
+// Complete additions and doublings (elementwise).
+static int32_t add_op(cheetah_ctx* ctx, bool host, const u64* lhs, int lhs_form, const u64* rhs, int rhs_form, u64* out, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (lhs_form != CHEETAH_PROJECTIVE && lhs_form != CHEETAH_JACOBIAN)
+        return fail(ctx, CHEETAH_ERR_INVALID, "lhs_form must be CHEETAH_PROJECTIVE or CHEETAH_JACOBIAN");
+    if (rhs_form != CHEETAH_AFFINE && rhs_form != lhs_form)
+        return fail(ctx, CHEETAH_ERR_INVALID, "rhs_form must be CHEETAH_AFFINE (mixed addition) or equal to lhs_form");
+    Op op;
+    op.n = n;
+    op.io = {in_(lhs, 18 * 8), in_(rhs, form_limbs(rhs_form) * 8), out_(out, 18 * 8)};
+    op.launch = [lhs_form, rhs_form](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0]) || !aligned8(d[1]) || !aligned8(d[2]))
+            return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        const int grid = ew_grid(c, cnt);
+#define LAUNCH(L, R) hipLaunchKernelGGL((k_add<L, R>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), at<u64>(d, 2), cnt)
+        if (lhs_form == CHEETAH_PROJECTIVE) {
+            if (rhs_form == CHEETAH_AFFINE) LAUNCH(1, 0);
+            else LAUNCH(1, 1);
+        } else {
+            if (rhs_form == CHEETAH_AFFINE) LAUNCH(2, 0);
+            else LAUNCH(2, 2);
+        }
+#undef LAUNCH
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
+static int32_t double_op(cheetah_ctx* ctx, bool host, const u64* pts, int form, u64* out, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (form != CHEETAH_PROJECTIVE && form != CHEETAH_JACOBIAN)
+        return fail(ctx, CHEETAH_ERR_INVALID, "form must be CHEETAH_PROJECTIVE or CHEETAH_JACOBIAN");
+    Op op;
+    op.n = n;
+    op.io = {in_(pts, 18 * 8), out_(out, 18 * 8)};
+    op.launch = [form](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0]) || !aligned8(d[1])) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        const int grid = ew_grid(c, cnt);
+        if (form == CHEETAH_PROJECTIVE)
+            hipLaunchKernelGGL((k_double<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt);
+        else
+            hipLaunchKernelGGL((k_double<2>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
+extern "C" int32_t cheetah_add_batch_dev(cheetah_ctx* ctx, const uint64_t* lhs, int lhs_form, const uint64_t* rhs, int rhs_form,
+                                         uint64_t* out, size_t n) {
+    return add_op(ctx, false, lhs, lhs_form, rhs, rhs_form, out, n);
+}
+extern "C" int32_t cheetah_add_batch(cheetah_ctx* ctx, const uint64_t* lhs, int lhs_form, const uint64_t* rhs, int rhs_form,
+                                     uint64_t* out, size_t n) {
+    return add_op(ctx, true, lhs, lhs_form, rhs, rhs_form, out, n);
+}
+extern "C" int32_t cheetah_double_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
+    return double_op(ctx, false, pts, form, out, n);
+}
+extern "C" int32_t cheetah_double_batch(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
+    return double_op(ctx, true, pts, form, out, n);
+}
+
 // -------------------------------------------------------------- encodings -----
 
 template <int REC>

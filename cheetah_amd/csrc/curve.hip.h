@@ -239,6 +239,141 @@ CH_DEV MJac mjac_add_mixed_unchecked_fresh_z4(const MJac& s, const Affine& r) {
     return mjac_add_mixed_impl<true, WANT_Z4>(s, r);
 }
 
+// ---- complete group law (batch entry points cheetah_add_batch / cheetah_double_batch) ----
+
+// ProjectivePoint::add_mixed, src/curve/projective.rs:518-569 (Renes-Costello-Batina Algorithm 2 with Z2 = 1;
+// returns s when r is the identity).
+CH_DEV Proj proj_add_mixed(const Proj& s, const Affine& r) {
+    Fp6 t0 = fp6_mul(s.x, r.x);
+    Fp6 t1 = fp6_mul(s.y, r.y);
+    Fp6 t3 = fp6_add(r.x, r.y);
+    Fp6 t4 = fp6_add(s.x, s.y);
+    t3 = fp6_mul(t3, t4);
+    t4 = fp6_add(t0, t1);
+    t3 = fp6_sub(t3, t4);
+    t4 = fp6_mul(r.x, s.z);
+    t4 = fp6_add(t4, s.x);
+    Fp6 t5 = fp6_mul(r.y, s.z);
+    t5 = fp6_add(t5, s.y);
+    Fp6 x3 = fp6_mul_by_3b(s.z);
+    Fp6 z3 = fp6_add(x3, t4);
+    x3 = fp6_sub(t1, z3);
+    z3 = fp6_add(t1, z3);
+    Fp6 y3 = fp6_mul(x3, z3);
+    t1 = fp6_double(t0);
+    t1 = fp6_add(t1, t0);
+    t4 = fp6_mul_by_3b(t4);
+    t1 = fp6_add(t1, s.z);
+    Fp6 t2 = fp6_sub(t0, s.z);
+    t4 = fp6_add(t4, t2);
+    t0 = fp6_mul(t1, t4);
+    y3 = fp6_add(y3, t0);
+    t0 = fp6_mul(t5, t4);
+    x3 = fp6_mul(t3, x3);
+    x3 = fp6_sub(x3, t0);
+    t0 = fp6_mul(t3, t1);
+    z3 = fp6_mul(t5, z3);
+    z3 = fp6_add(z3, t0);
+    Proj o;
+    o.x = fp6_select(x3, s.x, r.inf);
+    o.y = fp6_select(y3, s.y, r.inf);
+    o.z = fp6_select(z3, s.z, r.inf);
+    return o;
+}
+
+CH_DEV Proj jac_identity() {  // JacobianPoint::identity() = (1, 1, 0), src/curve/jacobian.rs:223-229
+    Proj p;
+    p.x = fp6_one();
+    p.y = fp6_one();
+    p.z = fp6_zero();
+    return p;
+}
+
+// JacobianPoint::double, src/curve/jacobian.rs:368-402: the modified-Jacobian doubling above on (x, y, z, (z^2)^2)
+// reaches the same x3, y3, z3 (z_sq2 there is z4 here); then the identity selection.
+CH_DEV Proj jac_double(const Proj& s) {
+    MJac m;
+    m.x = s.x;
+    m.y = s.y;
+    m.z = s.z;
+    m.z4 = fp6_square(fp6_square(s.z));
+    m = mjac_double_impl<false>(m);
+    Proj o;
+    o.x = m.x;
+    o.y = m.y;
+    o.z = m.z;
+    if (fp6_is_zero(s.z)) o = jac_identity();
+    return o;
+}
+
+// JacobianPoint::add, src/curve/jacobian.rs:452-505.  The reference's two ct_eq calls (rhs == -self, rhs == self,
+// src/curve/jacobian.rs:134-154) compare x z'^2 with x' z^2 and y z'^3 with y' z^3: those are a, b, c, d of the
+// formula itself, so the comparisons are e == 0, f == 0 and c + d == 0 and cost no product.  Selections in the
+// reference's order.
+CH_DEV Proj jac_add(const Proj& s, const Proj& r) {
+    Fp6 z1_sq = fp6_square(s.z);
+    Fp6 z2_sq = fp6_square(r.z);
+    Fp6 a = fp6_mul(s.x, z2_sq);
+    Fp6 b = fp6_mul(r.x, z1_sq);
+    Fp6 c = fp6_mul(r.z, z2_sq);
+    c = fp6_mul(c, s.y);
+    Fp6 d = fp6_mul(s.z, z1_sq);
+    d = fp6_mul(d, r.y);
+    Fp6 e = fp6_sub(b, a);
+    Fp6 f = fp6_sub(d, c);
+    const bool sz = fp6_is_zero(s.z), rz = fp6_is_zero(r.z);
+    const bool same_x = fp6_is_zero(e);
+    const bool is_same = (sz && rz) || (!sz && !rz && same_x && fp6_is_zero(f));
+    const bool is_neg = (sz && rz) || (!sz && !rz && same_x && fp6_is_zero(fp6_add(c, d)));
+    Fp6 e_sq = fp6_square(e);
+    Fp6 e_sq_e = fp6_mul(e, e_sq);
+    Fp6 a_e_sq = fp6_mul(a, e_sq);
+    Proj o;
+    o.x = fp6_square(f);
+    o.x = fp6_sub(o.x, e_sq_e);
+    o.x = fp6_sub(o.x, fp6_double(a_e_sq));
+    o.y = fp6_sub(a_e_sq, o.x);
+    o.y = fp6_mul(o.y, f);
+    o.y = fp6_sub(o.y, fp6_mul(c, e_sq_e));
+    o.z = fp6_mul(fp6_mul(s.z, r.z), e);
+    if (sz) o = r;
+    if (rz) o = s;
+    if (is_neg) o = jac_identity();
+    if (is_same) o = jac_double(s);
+    return o;
+}
+
+// JacobianPoint::add_mixed, src/curve/jacobian.rs:508-552.  The reference converts self and -self to affine (one
+// Fp6 inversion each, src/curve/affine.rs:86-101) for its two comparisons with rhs; x / z^2 == x' is x == x' z^2
+// for z != 0, so here they are e == 0, f == 0 and d + y == 0 on values the formula already has.
+CH_DEV Proj jac_add_mixed(const Proj& s, const Affine& r) {
+    Fp6 z1_sq = fp6_square(s.z);
+    Fp6 b = fp6_mul(r.x, z1_sq);
+    Fp6 d = fp6_mul(s.z, z1_sq);
+    d = fp6_mul(d, r.y);
+    Fp6 e = fp6_sub(b, s.x);
+    Fp6 f = fp6_sub(d, s.y);
+    const bool sz = fp6_is_zero(s.z);
+    const bool same_x = fp6_is_zero(e);
+    const bool is_same = (sz && r.inf) || (!sz && !r.inf && same_x && fp6_is_zero(f));
+    const bool is_neg = (sz && r.inf) || (!sz && !r.inf && same_x && fp6_is_zero(fp6_add(d, s.y)));
+    Fp6 e_sq = fp6_square(e);
+    Fp6 e_sq_e = fp6_mul(e, e_sq);
+    Fp6 x_e_sq = fp6_mul(s.x, e_sq);
+    Proj o;
+    o.x = fp6_square(f);
+    o.x = fp6_sub(o.x, e_sq_e);
+    o.x = fp6_sub(o.x, fp6_double(x_e_sq));
+    o.y = fp6_sub(x_e_sq, o.x);
+    o.y = fp6_mul(o.y, f);
+    o.y = fp6_sub(o.y, fp6_mul(s.y, e_sq_e));
+    o.z = fp6_mul(s.z, e);
+    if (r.inf) o = s;
+    if (is_neg) o = jac_identity();
+    if (is_same) o = jac_double(s);
+    return o;
+}
+
 // Single-point normalisations (one Fp6 inversion each).
 // src/curve/affine.rs:64-78
 CH_DEV Affine affine_from_proj(const Proj& p) {

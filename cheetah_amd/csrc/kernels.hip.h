@@ -1407,6 +1407,35 @@ __global__ void __launch_bounds__(BLOCK) k_is_on_curve(const u64* __restrict__ p
     }
 }
 
+// Complete group law over a batch: out[i] = lhs[i] + rhs[i] (LHS_FORM 1: ProjectivePoint::add / add_mixed,
+// src/curve/projective.rs:456-569; 2: JacobianPoint::add / add_mixed, src/curve/jacobian.rs:452-552; RHS_FORM 0 = the
+// mixed forms, rhs affine with (0, 1) as the identity's encoding), and out[i] = 2 pts[i] (::double, projective.rs:349-393,
+// jacobian.rs:368-402).  The result is the reference's own representative, canonical limbs.
+template <int LHS_FORM, int RHS_FORM>
+__global__ void __launch_bounds__(BLOCK) k_add(const u64* __restrict__ lhs, const u64* __restrict__ rhs, u64* __restrict__ out,
+                                               size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const Proj s = load_proj(lhs + 18 * i);
+        Proj o;
+        if (RHS_FORM == 0) {
+            Affine r = load_affine(rhs + 12 * i);
+            r.inf = affine_is_identity_encoding(r.x, r.y);
+            o = LHS_FORM == 1 ? proj_add_mixed(s, r) : jac_add_mixed(s, r);
+        } else {
+            const Proj r = load_proj(rhs + 18 * i);
+            o = LHS_FORM == 1 ? proj_add(s, r) : jac_add(s, r);
+        }
+        store_proj(out, nullptr, i, o);
+    }
+}
+template <int FORM>
+__global__ void __launch_bounds__(BLOCK) k_double(const u64* __restrict__ pts, u64* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const Proj s = load_proj(pts + 18 * i);
+        store_proj(out, nullptr, i, FORM == 1 ? proj_double(s) : jac_double(s));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Synthetic inputs: the generator of cheetah_amd/synth.py on the device.
 CH_DEV u64 splitmix64(u64 seed, u64 idx) {

@@ -268,6 +268,42 @@ class Engine:
         self._check(self._lib.cheetah_is_on_curve_batch(self._h, p.ctypes.data, in_form, flags.ctypes.data, len(p)))
         return flags
 
+    def add_batch(self, lhs, rhs, lhs_form=JACOBIAN, rhs_form=None, out=None):
+        """out[i] = lhs[i] + rhs[i] by the complete formulas, in lhs_form (PROJECTIVE or JACOBIAN).  rhs_form == lhs_form
+        (the default): ProjectivePoint::add (src/curve/projective.rs:456-515) / JacobianPoint::add
+        (src/curve/jacobian.rs:452-505); rhs_form == AFFINE: ::add_mixed (projective.rs:518-569, jacobian.rs:508-552)."""
+        rhs_form = lhs_form if rhs_form is None else rhs_form
+        wr = self._out_width(rhs_form)
+        if _is_torch(lhs):
+            a, b = self._dev(lhs, 8, 18), self._dev(rhs, 8, wr)
+            if a.shape[0] != b.shape[0]:
+                raise ValueError("lhs and rhs must hold the same number of points")
+            out = self._empty((a.shape[0], 18), torch.uint64) if out is None else self._dev(out, 8, 18)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_add_batch_dev(self._h, a.data_ptr(), lhs_form, b.data_ptr(), rhs_form, out.data_ptr(),
+                                                        a.shape[0]))
+            return out
+        a, b = self._np(lhs, np.uint64, 18), self._np(rhs, np.uint64, wr)
+        if len(a) != len(b):
+            raise ValueError("lhs and rhs must hold the same number of points")
+        out = np.empty((len(a), 18), np.uint64)
+        self._check(self._lib.cheetah_add_batch(self._h, a.ctypes.data, lhs_form, b.ctypes.data, rhs_form, out.ctypes.data, len(a)))
+        return out
+
+    def double_batch(self, pts, form=JACOBIAN, out=None):
+        """out[i] = 2 pts[i]: ProjectivePoint::double (src/curve/projective.rs:349-393) or JacobianPoint::double
+        (src/curve/jacobian.rs:368-402)."""
+        if _is_torch(pts):
+            a = self._dev(pts, 8, 18)
+            out = self._empty((a.shape[0], 18), torch.uint64) if out is None else self._dev(out, 8, 18)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_double_batch_dev(self._h, a.data_ptr(), form, out.data_ptr(), a.shape[0]))
+            return out
+        a = self._np(pts, np.uint64, 18)
+        out = np.empty((len(a), 18), np.uint64)
+        self._check(self._lib.cheetah_double_batch(self._h, a.ctypes.data, form, out.ctypes.data, len(a)))
+        return out
+
     # -- multi-scalar ladders, subgroup check, cofactor clearing ----------------------
     def _many(self, fname, pts, scalars, m, ns, in_form, out_form):
         w, wi = self._out_width(out_form), self._out_width(in_form)

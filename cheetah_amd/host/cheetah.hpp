@@ -267,6 +267,32 @@ inline std::vector<ProjectivePoint> clear_cofactor_batch(const Context& ctx, con
     return out;
 }
 
+// ---- complete group law over batches ------------------------------------------------
+// &ProjectivePoint + &ProjectivePoint = ProjectivePoint::add, src/curve/projective.rs:456-515
+inline std::vector<ProjectivePoint> add_batch(const Context& ctx, const std::vector<ProjectivePoint>& lhs,
+                                              const std::vector<ProjectivePoint>& rhs) {
+    if (lhs.size() != rhs.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<ProjectivePoint> out(lhs.size());
+    ctx.check(cheetah_add_batch(ctx.get(), u64p(lhs.data()), CHEETAH_PROJECTIVE, u64p(rhs.data()), CHEETAH_PROJECTIVE, u64p(out.data()),
+                                lhs.size()));
+    return out;
+}
+// ProjectivePoint::add_mixed, src/curve/projective.rs:518-569 ((0, 1) is the affine identity)
+inline std::vector<ProjectivePoint> add_mixed_batch(const Context& ctx, const std::vector<ProjectivePoint>& lhs,
+                                                    const std::vector<AffinePoint>& rhs) {
+    if (lhs.size() != rhs.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<ProjectivePoint> out(lhs.size());
+    ctx.check(cheetah_add_batch(ctx.get(), u64p(lhs.data()), CHEETAH_PROJECTIVE, u64p(rhs.data()), CHEETAH_AFFINE, u64p(out.data()),
+                                lhs.size()));
+    return out;
+}
+// ProjectivePoint::double, src/curve/projective.rs:349-393
+inline std::vector<ProjectivePoint> double_batch(const Context& ctx, const std::vector<ProjectivePoint>& p) {
+    std::vector<ProjectivePoint> out(p.size());
+    ctx.check(cheetah_double_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, u64p(out.data()), p.size()));
+    return out;
+}
+
 // ---- point encodings (src/curve/encoding.rs) ---------------------------------------
 struct CompressedPoint {
     std::array<uint8_t, 49> bytes;  // src/curve/encoding.rs:29

@@ -241,6 +241,26 @@ int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, 
 int32_t cheetah_is_on_curve_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint8_t *flags, size_t n);
 int32_t cheetah_is_on_curve_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, uint8_t *flags, size_t n);
 
+/* ---- group law on batches (the complete formulas) -----------------------------------
+ * out[i] = lhs[i] + rhs[i], lhs and out as n x 18 limbs in lhs_form, which is CHEETAH_PROJECTIVE or CHEETAH_JACOBIAN:
+ *   rhs_form == lhs_form      ProjectivePoint::add        src/curve/projective.rs:456-515
+ *                             JacobianPoint::add          src/curve/jacobian.rs:452-505
+ *   rhs_form == CHEETAH_AFFINE  ProjectivePoint::add_mixed  src/curve/projective.rs:518-569
+ *                             JacobianPoint::add_mixed    src/curve/jacobian.rs:508-552
+ *                             (rhs as n x 12 limbs, (0, 1) = the identity, as for every affine input here)
+ * out[i] = 2 pts[i]           ProjectivePoint::double     src/curve/projective.rs:349-393
+ *                             JacobianPoint::double       src/curve/jacobian.rs:368-402
+ * Parity level L2: out[i] is the representative (X : Y : Z) the reference's method returns, canonical limbs,
+ * including which representative its special cases select (JacobianPoint::identity() = (1, 1, 0) for P + (-P),
+ * self.double() for P + P, the other operand as is when one is the identity).  Inputs need not be canonical and are
+ * not checked for curve membership (the reference's methods do not check either).  out may alias lhs or pts. */
+int32_t cheetah_add_batch(cheetah_ctx *ctx, const uint64_t *lhs, int lhs_form, const uint64_t *rhs, int rhs_form,
+                          uint64_t *out, size_t n);
+int32_t cheetah_add_batch_dev(cheetah_ctx *ctx, const uint64_t *lhs, int lhs_form, const uint64_t *rhs, int rhs_form,
+                              uint64_t *out, size_t n);
+int32_t cheetah_double_batch(cheetah_ctx *ctx, const uint64_t *pts, int form, uint64_t *out, size_t n);
+int32_t cheetah_double_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form, uint64_t *out, size_t n);
+
 /* ---- point encodings (src/curve/encoding.rs) ------------------------------------
  * cheetah_encode_uncompressed_batch  AffinePoint::to_uncompressed = UncompressedPoint::from_affine   :169-183
  *                                    97 bytes: x | y canonical little-endian (zeros for the identity), flag byte bit 7 = infinity

@@ -80,6 +80,12 @@ def lib():
         "ora_jac_double": (None, [u64p, u64p]),
         "ora_jac_double_unchecked": (None, [u64p, u64p]),
         "ora_jac_add_mixed_unchecked": (None, [u64p, u64p, C.c_uint8, u64p]),
+        "ora_jac_add": (None, [u64p, u64p, u64p]),
+        "ora_jac_add_mixed": (None, [u64p, u64p, C.c_uint8, u64p]),
+        "ora_jac_eq": (C.c_int, [u64p, u64p]),
+        "ora_proj_eq": (C.c_int, [u64p, u64p]),
+        "ora_add_batch": (None, [u64p, C.c_int, u64p, C.c_int, u64p, C.c_size_t]),
+        "ora_double_batch": (None, [u64p, C.c_int, u64p, C.c_size_t]),
         "ora_jac_to_affine": (None, [u64p, u64p, u8p]),
         "ora_jac_is_on_curve": (C.c_int, [u64p]),
         "ora_mjac_double_unchecked": (None, [u64p, u64p]),
@@ -303,3 +309,21 @@ def is_on_curve_batch(pts, in_form):
     p = _u64(pts)
     f = {0: lib().ora_affine_is_on_curve, 1: lib().ora_proj_is_on_curve, 2: lib().ora_jac_is_on_curve}[in_form]
     return np.array([f(p[i]) for i in range(len(p))], np.uint8)
+
+
+def add_batch(lhs, lhs_form, rhs, rhs_form):
+    """Complete additions: ProjectivePoint::add / add_mixed (src/curve/projective.rs:456-569),
+    JacobianPoint::add / add_mixed (src/curve/jacobian.rs:452-552); the result in lhs_form."""
+    a = _u64(lhs).reshape(-1, 18)
+    b = _u64(rhs).reshape(len(a), 12 if rhs_form == 0 else 18)
+    out = np.empty((len(a), 18), np.uint64)
+    lib().ora_add_batch(a, lhs_form, b, rhs_form, out, len(a))
+    return out
+
+
+def double_batch(pts, form):
+    """ProjectivePoint::double (src/curve/projective.rs:349-393) / JacobianPoint::double (src/curve/jacobian.rs:368-402)."""
+    a = _u64(pts).reshape(-1, 18)
+    out = np.empty_like(a)
+    lib().ora_double_batch(a, form, out, len(a))
+    return out

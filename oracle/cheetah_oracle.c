@@ -799,11 +799,88 @@ static proj jac_double_unchecked(proj s) {
     return o;
 }
 
+static proj jac_add_mixed_unchecked(proj s, affine r);
+static inline proj jac_identity(void) { /* JacobianPoint::identity() = (1, 1, 0), src/curve/jacobian.rs:223-229 */
+    proj p = {FP6_ONE, FP6_ONE, FP6_ZERO};
+    return p;
+}
+
 /* src/curve/jacobian.rs:368-402 */
 static proj jac_double(proj s) {
     proj o = jac_double_unchecked(s); /* identical arithmetic sequence */
-    if (fp6_is_zero(s.z)) return proj_identity();
+    if (fp6_is_zero(s.z)) return jac_identity();
     return o;
+}
+
+/* ConstantTimeEq for JacobianPoint, src/curve/jacobian.rs:134-154 */
+static int jac_eq(proj s, proj o) {
+    fp6 z1_squared = fp6_square(s.z);
+    fp6 z2_squared = fp6_square(o.z);
+    fp6 x1 = fp6_mul(s.x, z2_squared);
+    fp6 x2 = fp6_mul(o.x, z1_squared);
+    fp6 y1 = fp6_mul(fp6_mul(s.y, z2_squared), o.z);
+    fp6 y2 = fp6_mul(fp6_mul(o.y, z1_squared), s.z);
+    int sz = fp6_is_zero(s.z), oz = fp6_is_zero(o.z);
+    return (sz & oz) | (!sz & !oz & fp6_eq(x1, x2) & fp6_eq(y1, y2));
+}
+/* ConstantTimeEq for ProjectivePoint, src/curve/projective.rs:118-135 */
+static int proj_eq(proj s, proj o) {
+    fp6 x1 = fp6_mul(s.x, o.z);
+    fp6 x2 = fp6_mul(o.x, s.z);
+    fp6 y1 = fp6_mul(s.y, o.z);
+    fp6 y2 = fp6_mul(o.y, s.z);
+    int sz = fp6_is_zero(s.z), oz = fp6_is_zero(o.z);
+    return (sz & oz) | (!sz & !oz & fp6_eq(x1, x2) & fp6_eq(y1, y2));
+}
+/* ConstantTimeEq for AffinePoint, src/curve/affine.rs:132-144 */
+static int affine_eq(affine a, affine b) {
+    return (a.inf & b.inf) | (!a.inf & !b.inf & fp6_eq(a.x, b.x) & fp6_eq(a.y, b.y));
+}
+static inline proj jac_neg(proj s) { /* src/curve/jacobian.rs:443-449 */
+    proj r = {s.x, fp6_neg(s.y), s.z};
+    return r;
+}
+
+/* JacobianPoint::add, src/curve/jacobian.rs:452-505: the chord formula, then the four selections in the
+ * reference's order (self identity -> rhs; rhs identity -> self; rhs == -self -> identity; rhs == self -> double) */
+static proj jac_add(proj s, proj r) {
+    fp6 z1_sq = fp6_square(s.z);
+    fp6 z2_sq = fp6_square(r.z);
+    fp6 a = fp6_mul(s.x, z2_sq);
+    fp6 b = fp6_mul(r.x, z1_sq);
+    fp6 c = fp6_mul(r.z, z2_sq);
+    c = fp6_mul(c, s.y);
+    fp6 d = fp6_mul(s.z, z1_sq);
+    d = fp6_mul(d, r.y);
+    fp6 e = fp6_sub(b, a);
+    fp6 f = fp6_sub(d, c);
+    fp6 e_sq = fp6_square(e);
+    fp6 e_sq_e = fp6_mul(e, e_sq);
+    fp6 a_e_sq = fp6_mul(a, e_sq);
+    fp6 x3 = fp6_square(f);
+    x3 = fp6_sub(x3, e_sq_e);
+    x3 = fp6_sub(x3, fp6_double(a_e_sq));
+    fp6 y3 = fp6_sub(a_e_sq, x3);
+    y3 = fp6_mul(y3, f);
+    fp6 t3 = fp6_mul(c, e_sq_e);
+    y3 = fp6_sub(y3, t3);
+    fp6 z3 = fp6_mul(s.z, r.z);
+    z3 = fp6_mul(z3, e);
+    proj tmp = {x3, y3, z3};
+    if (fp6_is_zero(s.z)) tmp = r;
+    if (fp6_is_zero(r.z)) tmp = s;
+    if (jac_eq(r, jac_neg(s))) tmp = jac_identity();
+    if (jac_eq(r, s)) tmp = jac_double(s);
+    return tmp;
+}
+
+/* JacobianPoint::add_mixed, src/curve/jacobian.rs:508-552.  Its two comparisons go through
+ * AffinePoint::from(JacobianPoint) (one Fp6 inversion each, src/curve/affine.rs:86-101), restated as such. */
+static proj jac_add_mixed(proj s, affine r) {
+    proj tmp = jac_add_mixed_unchecked(s, r); /* identical sequence, including the rhs-identity selection */
+    if (affine_eq(r, affine_from_jac(jac_neg(s)))) tmp = jac_identity();
+    if (affine_eq(r, affine_from_jac(s))) tmp = jac_double(s);
+    return tmp;
 }
 
 /* src/curve/jacobian.rs:559-595 */
@@ -893,6 +970,12 @@ void ora_jac_double_unchecked(const u64 *p, u64 *o) { proj_store(o, jac_double_u
 void ora_jac_add_mixed_unchecked(const u64 *p, const u64 *q, uint8_t qi, u64 *o) {
     proj_store(o, jac_add_mixed_unchecked(proj_load(p), affine_load(q, qi)));
 }
+void ora_jac_add(const u64 *p, const u64 *q, u64 *o) { proj_store(o, jac_add(proj_load(p), proj_load(q))); }
+void ora_jac_add_mixed(const u64 *p, const u64 *q, uint8_t qi, u64 *o) {
+    proj_store(o, jac_add_mixed(proj_load(p), affine_load(q, qi)));
+}
+int ora_jac_eq(const u64 *p, const u64 *q) { return jac_eq(proj_load(p), proj_load(q)); }
+int ora_proj_eq(const u64 *p, const u64 *q) { return proj_eq(proj_load(p), proj_load(q)); }
 void ora_jac_to_affine(const u64 *p, u64 *xy, uint8_t *inf) { affine_store(xy, inf, affine_from_jac(proj_load(p))); }
 int ora_jac_is_on_curve(const u64 *p) { return jac_is_on_curve(proj_load(p)); }
 static inline mjac mjac_load(const u64 *p) {
@@ -1333,6 +1416,32 @@ void ora_basepoint_table_multiply_batch(const u64 *table_xy, const uint8_t *tabl
         for (int k = 0; k < 4; k++) acc = proj_double_unchecked(acc);
         for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lookup_get_point(tab[j / 2], 8, a[j]));
         emit_point(proj_add_mixed_unchecked(acc, G_MINUS_SHIFT[4]), 0, out, out_inf, i, out_form);
+    }
+}
+/* out[i] = lhs[i] + rhs[i] with the complete formulas.  lhs_form 1: ProjectivePoint::add (src/curve/projective.rs:456-515) or,
+ * rhs_form 0, ::add_mixed (518-569); lhs_form 2: JacobianPoint::add (src/curve/jacobian.rs:452-505) or ::add_mixed (508-552).
+ * out: the reference's own representative in lhs_form, canonical limbs. */
+void ora_add_batch(const u64 *lhs, int lhs_form, const u64 *rhs, int rhs_form, u64 *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        proj s = proj_load(lhs + 18 * i), o;
+        if (rhs_form == 0) {
+            affine r = affine_load(rhs + 12 * i, 0);
+            r.inf = (uint8_t)(fp6_is_zero(r.x) && fp6_eq(r.y, FP6_ONE));
+            o = lhs_form == 1 ? proj_add_mixed(s, r) : jac_add_mixed(s, r);
+        } else {
+            proj r = proj_load(rhs + 18 * i);
+            o = lhs_form == 1 ? proj_add(s, r) : jac_add(s, r);
+        }
+        emit_point(o, 0, out, NULL, i, 1);
+    }
+}
+/* ProjectivePoint::double (src/curve/projective.rs:349-393) / JacobianPoint::double (src/curve/jacobian.rs:368-402) */
+void ora_double_batch(const u64 *pts, int form, u64 *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        proj s = proj_load(pts + 18 * i);
+        emit_point(form == 1 ? proj_double(s) : jac_double(s), 0, out, NULL, i, 1);
     }
 }
 /* AffinePoint::is_on_curve, src/curve/affine.rs:364-368; (0, 1) is the identity's encoding at the ABI */

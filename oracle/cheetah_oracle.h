@@ -124,6 +124,14 @@ void ora_basepoint_table_create(const uint64_t *p_in, int in_form, uint64_t *out
 void ora_basepoint_table_multiply_batch(const uint64_t *table_xy, const uint8_t *table_inf, const uint8_t *scalars, uint64_t *out,
                                         uint8_t *out_inf, size_t n, int out_form);
 int ora_affine_is_on_curve(const uint64_t *xy); /* src/curve/affine.rs:364-368 */
+/* complete group law: JacobianPoint::add / add_mixed (src/curve/jacobian.rs:452-552), the two ct_eq (jacobian.rs:134-154,
+ * projective.rs:118-135), and batch drivers over ProjectivePoint / JacobianPoint ::add, ::add_mixed, ::double */
+void ora_jac_add(const uint64_t *p, const uint64_t *q, uint64_t *out);
+void ora_jac_add_mixed(const uint64_t *p, const uint64_t *q_xy, uint8_t q_inf, uint64_t *out);
+int ora_jac_eq(const uint64_t *p, const uint64_t *q);
+int ora_proj_eq(const uint64_t *p, const uint64_t *q);
+void ora_add_batch(const uint64_t *lhs, int lhs_form, const uint64_t *rhs, int rhs_form, uint64_t *out, size_t n);
+void ora_double_batch(const uint64_t *pts, int form, uint64_t *out, size_t n);
 int ora_num_threads(void);
 void ora_fp6_mul_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 void ora_fp6_square_batch(const uint64_t *a, uint64_t *out, size_t n);

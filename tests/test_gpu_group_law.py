@@ -1,0 +1,167 @@
+"""GPU parity of the complete group law over batches (cheetah_add_batch / cheetah_double_batch, include/cheetah_hip.h):
+ProjectivePoint::add / add_mixed / double (src/curve/projective.rs:456-569, :349-393) and JacobianPoint::add / add_mixed /
+double (src/curve/jacobian.rs:452-552, :368-402) against the oracle's restatement on the same seeded inputs, with every
+special case the formulas select on (either operand the identity, both, P + P, P + (-P), equal points in different
+representatives) placed in the batch.  Bar: bit-exact, parity level L2 (the reference's own (X : Y : Z))."""
+import numpy as np
+import pytest
+
+from cheetah_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+AFFINE, PROJECTIVE, JACOBIAN = 0, 1, 2
+P = 0xFFFFFFFF00000001
+IDENT_AFF = np.array([0] * 6 + [1] + [0] * 5, np.uint64)
+IDENT = {PROJECTIVE: np.array([0] * 6 + [1] + [0] * 5 + [0] * 6, np.uint64),
+         JACOBIAN: np.array([1] + [0] * 5 + [1] + [0] * 5 + [0] * 6, np.uint64)}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cheetah_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda().view(torch.uint64)
+
+
+def host(t):
+    import torch
+    return t.view(torch.int64).cpu().numpy().view(np.uint64)
+
+
+def representatives(eng, ora, aff, zs, form):
+    """(x, y) -> (x z, y z, z) or (x z^2, y z^3, z), limbs left non-canonical where the products are."""
+    n = len(aff)
+    x, y = aff[:, :6], aff[:, 6:]
+    z = zs.reshape(n, 6)
+    if form == PROJECTIVE:
+        return np.concatenate([ora.fp6_mul_batch(x, z).reshape(n, 6), ora.fp6_mul_batch(y, z).reshape(n, 6), z], axis=1)
+    z2 = ora.fp6_square_batch(z).reshape(n, 6)
+    z3 = ora.fp6_mul_batch(z2, z).reshape(n, 6)
+    return np.concatenate([ora.fp6_mul_batch(x, z2).reshape(n, 6), ora.fp6_mul_batch(y, z3).reshape(n, 6), z], axis=1)
+
+
+def negate(p):
+    q = p.copy()
+    q[:, 6:12] = (np.uint64(P) - q[:, 6:12] % np.uint64(P)) % np.uint64(P)
+    return q
+
+
+def special_cases(eng, ora, form, n, seed):
+    """lhs (n x 18), rhs (n x 18), rhs_affine (n x 12): random pairs with the special cases at fixed slots."""
+    sc = synth.scalars(seed, 2 * n)
+    aff, _ = eng.mul_by_generator_batch(sc, AFFINE)
+    a, b = aff[:n].copy(), aff[n:].copy()
+    for i in range(0, n, 16):
+        b[i] = a[i]                                   # P + P (different representatives below)
+    for i in range(5, n, 16):
+        b[i] = negate(np.concatenate([a[i], np.zeros(6, np.uint64)])[None, :])[0, :12]   # P + (-P)
+    zs = synth.fp6_elements(seed + 1, 2 * n).reshape(2 * n, 6)
+    lhs = representatives(eng, ora, a, zs[:n], form)
+    rhs = representatives(eng, ora, b, zs[n:], form)
+    for i in range(3, n, 16):
+        lhs[i] = IDENT[form]                          # O + Q
+    for i in range(7, n, 16):
+        rhs[i] = IDENT[form]                          # P + O
+        b[i] = IDENT_AFF
+    for i in range(11, n, 16):
+        lhs[i] = IDENT[form]                          # O + O
+        rhs[i] = IDENT[form]
+        b[i] = IDENT_AFF
+    for i in range(13, n, 16):                        # an identity with other x, y: z = 0 is what counts
+        lhs[i, 12:] = 0
+    for i in range(14, n, 32):                        # the very same representative on both sides
+        rhs[i] = lhs[i]
+        b[i] = a[i]
+    return lhs, rhs, b
+
+
+@pytest.mark.parametrize("form", [PROJECTIVE, JACOBIAN])
+def test_add_and_double_match_the_oracle(eng, ora, form):
+    n = 4096
+    lhs, rhs, rhs_aff = special_cases(eng, ora, form, n, 300 + form)
+    want = ora.add_batch(lhs, form, rhs, form)
+    got = host(eng.add_batch(dev(lhs), dev(rhs), form))
+    assert np.array_equal(got, want)
+    want_m = ora.add_batch(lhs, form, rhs_aff, AFFINE)
+    got_m = host(eng.add_batch(dev(lhs), dev(rhs_aff), form, AFFINE))
+    assert np.array_equal(got_m, want_m)
+    want_d = ora.double_batch(lhs, form)
+    got_d = host(eng.double_batch(dev(lhs), form))
+    assert np.array_equal(got_d, want_d)
+    # the special cases came out as the reference selects them
+    if form == JACOBIAN:
+        assert np.array_equal(got[5], IDENT[JACOBIAN]) and np.array_equal(got_m[5], IDENT[JACOBIAN])   # P + (-P) = (1, 1, 0)
+        assert np.array_equal(got[0], got_d[0]) and np.array_equal(got_m[0], got_d[0])                 # P + P = P.double()
+        assert np.array_equal(got[11], IDENT[JACOBIAN]) and np.array_equal(got_d[11], IDENT[JACOBIAN])
+        assert np.array_equal(got[3], rhs[3] % np.uint64(P)) and np.array_equal(got[7], lhs[7] % np.uint64(P))
+        # JacobianPoint::add_mixed has no selection for "self is the identity, rhs is not" (src/curve/jacobian.rs:543-551):
+        # its chord formula then returns z3 = z e = 0, i.e. O + Q comes out as an identity.  Reproduced, not repaired.
+        assert not got_m[3, 12:].any() and got[3, 12:].any()
+    else:
+        assert not got[5, 12:].any() and not got[11, 12:].any() and np.array_equal(got_d[11], IDENT[PROJECTIVE])
+        # ProjectivePoint::add_mixed is complete in its left operand: O + Q = Q
+        xy, inf = eng.batch_normalize(got_m[3:4], PROJECTIVE)
+        assert np.array_equal(xy[0], rhs_aff[3]) and inf[0] == 0
+    assert np.array_equal(got_m[7], lhs[7] % np.uint64(P))
+    # host-array entry points: the same results
+    assert np.array_equal(eng.add_batch(lhs, rhs, form), want)
+    assert np.array_equal(eng.add_batch(lhs, rhs_aff, form, AFFINE), want_m)
+    assert np.array_equal(eng.double_batch(lhs, form), want_d)
+    # in place: out may alias lhs
+    buf = dev(lhs)
+    eng.add_batch(buf, dev(rhs), form, out=buf)
+    assert np.array_equal(host(buf), want)
+
+
+@pytest.mark.parametrize("form", [PROJECTIVE, JACOBIAN])
+def test_group_law_properties_at_scale(eng, ora, form):
+    """2^20 points: (P + Q) + R and P + (Q + R) normalise to the same affine points; P + P and P.double() too;
+    k G + G == (k + 1) G against the fixed-base path."""
+    import torch
+    n = 1 << 20
+    sc = synth.scalars(77, n)
+    k = torch.from_numpy(sc).cuda()
+    out_form = form
+    p, _ = eng.mul_by_generator_batch(k, out_form)
+    q = torch.roll(p.view(torch.int64), 1, 0).view(torch.uint64)
+    r = torch.roll(p.view(torch.int64), 2, 0).view(torch.uint64)
+    left = eng.add_batch(eng.add_batch(p, q, form), r, form)
+    right = eng.add_batch(p, eng.add_batch(q, r, form), form)
+    la, li = eng.batch_normalize(left, form)
+    ra, ri = eng.batch_normalize(right, form)
+    assert torch.equal(la.view(torch.int64), ra.view(torch.int64)) and torch.equal(li, ri)
+    da, _ = eng.batch_normalize(eng.double_batch(p, form), form)
+    sa, _ = eng.batch_normalize(eng.add_batch(p, p, form), form)
+    assert torch.equal(da.view(torch.int64), sa.view(torch.int64))
+    # k G + G == (k + 1) G  (k + 1 computed on 256-bit little-endian integers; k < q - 1 for every seeded scalar)
+    g = torch.from_numpy(ora.table("ora_generator_affine", 1).view(np.int64)).cuda().expand(n, 12).contiguous().view(torch.uint64)
+    kp = sc.copy().reshape(n, 32)
+    carry = np.ones(n, np.uint16)
+    for b in range(32):
+        v = kp[:, b].astype(np.uint16) + carry
+        kp[:, b] = (v & 0xFF).astype(np.uint8)
+        carry = v >> 8
+    assert not carry.any()
+    want, _ = eng.mul_by_generator_batch(torch.from_numpy(kp).cuda(), AFFINE)
+    got, _ = eng.batch_normalize(eng.add_batch(p, g, form, AFFINE), form)
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+
+
+def test_add_batch_rejects_bad_forms(eng):
+    from cheetah_amd import CheetahError
+    a = np.zeros((4, 18), np.uint64)
+    with pytest.raises(CheetahError):
+        eng.add_batch(a, np.zeros((4, 12), np.uint64), AFFINE, AFFINE)
+    with pytest.raises(CheetahError):
+        eng.add_batch(a, a, PROJECTIVE, JACOBIAN)
+    with pytest.raises(CheetahError):
+        eng.double_batch(a, AFFINE)

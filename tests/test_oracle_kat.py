@@ -524,3 +524,122 @@ def test_decompression_and_from_x(ora, kats):
             rhs = M.f6_add(M.f6_add(M.f6_mul(M.f6_sqr(M.f6(xs[i])), M.f6(xs[i])), M.f6(xs[i])), M.B)
             assert M.f6_pow(rhs, (P ** 6 - 1) // 2) != M.ONE
     assert 0 < fsome[n + 2:].sum() < 8
+
+
+# ------------------------------------------- complete group law (oracle) ----
+
+def _rescale(xy, z, jac):
+    """(x, y) -> the representative with the given z: (x z, y z, z) or (x z^2, y z^3, z)."""
+    x, y = tuple(int(v) for v in xy[:6]), tuple(int(v) for v in xy[6:])
+    z = tuple(int(v) % P for v in z)
+    if jac:
+        z2 = M.f6_sqr(z)
+        return u64(M.f6_mul(x, z2) + M.f6_mul(y, M.f6_mul(z2, z)) + z)
+    return u64(M.f6_mul(x, z) + M.f6_mul(y, z) + z)
+
+
+def test_complete_additions_mirror_reference_tests(ora, kats):
+    """JacobianPoint::add / add_mixed / double and their projective counterparts, after
+    src/curve/jacobian.rs:1405-1609 and src/curve/projective.rs tests of the same names."""
+    L = ora.lib()
+    g = _aff(kats["generator"])
+    gj = _proj_of(g)
+    z = [0xa3c62f9770336022, 0x69a1531152c92fc1, 0x1636d9b90656a08a, 0x635289066593aaf6, 0x1e2178e3c54f6682,
+         0xe15458e6d847f393]  # src/curve/jacobian.rs:1455-1462
+    out, out2 = np.zeros(18, np.uint64), np.zeros(18, np.uint64)
+    jid = u64([1] + [0] * 5 + [1] + [0] * 5 + [0] * 6)     # JacobianPoint::identity(), src/curve/jacobian.rs:223-229
+    pid = u64([0] * 6 + [1] + [0] * 5 + [0] * 6)           # ProjectivePoint::identity(), src/curve/projective.rs:204-210
+    aid = u64([0] * 6 + [1] + [0] * 5)
+    # identity + identity, identity.double()
+    L.ora_jac_add(jid, jid, out)
+    assert list(out) == list(jid)
+    L.ora_jac_double(jid, out)
+    assert list(out) == list(jid)
+    L.ora_jac_add_mixed(jid, aid, 1, out)
+    assert list(out) == list(jid)
+    # identity + b, b + identity with b a rescaled generator: equal to the generator as points, b itself as coordinates
+    b = _rescale(g, z, True)
+    assert L.ora_jac_is_on_curve(b) == 1 and L.ora_jac_eq(b, gj) == 1 and L.ora_jac_eq(b, jid) == 0
+    L.ora_jac_add(jid, b, out)
+    assert list(out) == list(b)
+    L.ora_jac_add(b, jid, out)
+    assert list(out) == list(b)
+    L.ora_jac_add_mixed(b, aid, 1, out)
+    assert list(out) == list(b)
+    # equality is a relation on points: the negated representative differs, a broken x is off the curve
+    c = b.copy()
+    c[6:12] = (P - c[6:12]) % P
+    assert L.ora_jac_is_on_curve(c) == 1 and L.ora_jac_eq(c, gj) == 0
+    # 4G + 2G == G + 5 x G (add), == G + 5 x affine G (add_mixed)
+    two, four = np.zeros(18, np.uint64), np.zeros(18, np.uint64)
+    L.ora_jac_double(gj, two)
+    L.ora_jac_double(two, four)
+    L.ora_jac_add(four, two, out)
+    d, d2 = gj.copy(), gj.copy()
+    for _ in range(5):
+        L.ora_jac_add(d.copy(), gj, d)
+        L.ora_jac_add_mixed(d2.copy(), g, 0, d2)
+    assert L.ora_jac_is_on_curve(out) == 1 and L.ora_jac_eq(out, d) == 1 and L.ora_jac_eq(out, d2) == 1
+    six = M.scalar_mul(6, (tuple(kats["generator"]["x"]), tuple(kats["generator"]["y"])))
+    assert M.jac_to_affine([int(v) for v in out]) == six
+    # a + a takes the doubling branch: the same representative as a.double(); so does add_mixed with a's own affine form
+    L.ora_jac_add(b, b, out)
+    L.ora_jac_double(b, out2)
+    assert list(out) == list(out2)
+    L.ora_jac_add_mixed(b, g, 0, out)
+    assert list(out) == list(out2)
+    # ... which the unchecked formula cannot do (src/curve/jacobian.rs:1598-1599)
+    L.ora_jac_add_mixed_unchecked(b, g, 0, out)
+    assert L.ora_jac_eq(out, out2) == 0
+    # a + (-a) == identity, exactly (1, 1, 0) (src/curve/jacobian.rs:1605-1609)
+    L.ora_jac_add(two, u64(list(two[:6]) + [(P - int(v)) % P for v in two[6:12]] + list(two[12:])), out)
+    assert list(out) == list(jid)
+    neg_g = u64(list(g[:6]) + [(P - int(v)) % P for v in g[6:]])
+    L.ora_jac_add_mixed(b, neg_g, 0, out)
+    assert list(out) == list(jid)
+    # projective: equality, mixed addition with the identity, 4G + 2G
+    bp = _rescale(g, z, False)
+    gp = _proj_of(g)
+    assert L.ora_proj_is_on_curve(bp) == 1 and L.ora_proj_eq(bp, gp) == 1 and L.ora_proj_eq(bp, pid) == 0
+    L.ora_proj_add_mixed(bp, aid, 1, out)
+    assert list(out) == list(bp)
+    L.ora_proj_double(gp, two)
+    L.ora_proj_double(two, four)
+    L.ora_proj_add(four, two, out)
+    assert M.proj_to_affine([int(v) for v in out]) == six
+    d = gp.copy()
+    for _ in range(5):
+        L.ora_proj_add_mixed(d.copy(), g, 0, d)
+    assert L.ora_proj_eq(out, d) == 1
+
+
+def test_complete_additions_vs_affine_model(ora):
+    """Seeded points in random representatives: every complete formula lands on the model's affine chord-and-tangent
+    sum; add_mixed equals add_mixed_unchecked away from the special cases (src/curve/jacobian.rs:1589-1596)."""
+    n = 24
+    xy, _, ok = ora.affine_from_x_batch(synth.fp6_elements(71, 8 * n))
+    pts = xy[ok == 1][: 2 * n]
+    zs = synth.fp6_elements(72, 2 * n).reshape(-1, 6)
+    for jac in (False, True):
+        form = 2 if jac else 1
+        lhs = np.stack([_rescale(pts[i], zs[i], jac) for i in range(n)])
+        rhs = np.stack([_rescale(pts[n + i], zs[n + i], jac) for i in range(n)])
+        s = ora.add_batch(lhs, form, rhs, form)
+        sm = ora.add_batch(lhs, form, pts[n:], 0)
+        dd = ora.double_batch(lhs, form)
+        to_aff = M.jac_to_affine if jac else M.proj_to_affine
+        for i in range(n):
+            p1, p2 = M.limbs_to_affine([int(v) for v in pts[i]]), M.limbs_to_affine([int(v) for v in pts[n + i]])
+            want = M.aff_add(p1, p2)
+            assert to_aff([int(v) for v in s[i]]) == want
+            assert to_aff([int(v) for v in sm[i]]) == want
+            assert to_aff([int(v) for v in dd[i]]) == M.aff_add(p1, p1)
+        unchecked = np.zeros(18, np.uint64)
+        f = ora.lib().ora_jac_add_mixed_unchecked if jac else ora.lib().ora_proj_add_mixed_unchecked
+        eq = ora.lib().ora_jac_eq if jac else ora.lib().ora_proj_eq
+        for i in range(n):
+            f(lhs[i], pts[n + i], 0, unchecked)
+            if jac:
+                assert list(unchecked % np.uint64(P)) == list(sm[i])   # the same sequence, hence the same representative
+            else:
+                assert eq(unchecked, sm[i]) == 1                       # another formula: the same point
