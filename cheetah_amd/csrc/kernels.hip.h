@@ -312,45 +312,69 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
 // NLDS > 0 keeps the first NLDS prefix products of a chunk in LDS ([slot][limb][lane], 8-byte accesses, conflict
 // free) instead of registers; every (CHUNK, NLDS, waves) combination that does not spill measured 7.5 - 8.0 G/s
 // (chunk 4 - 12: the Fp6 inversion per chunk is not what bounds it), so the default is the simplest: 8, 0, 2.
+// Second series (same file): the trivial prefix (1) is no longer kept or multiplied (3 products fewer per chunk), the
+// forward pass requests z CH_BN_AHEAD steps ahead, and with the prefixes in LDS the kernel also runs at 3 and 4 waves
+// per SIMD without the backward prefetch (CH_BN_PREFETCH 0): 2.08 - 2.12 ms for every shape again.  tools/mem_pattern.hip
+// shows why: moving the records with no arithmetic at all takes 0.87 ms in this access pattern (0.77 ms with
+// wave-contiguous accesses), the VALU work alone is ~1.5 ms at the ladder kernels' issue rate, and the kernel needs
+// 70 % of the memory pipeline's capacity while it computes -- the two overlap, but not perfectly (2.1 ms lies between
+// max = 1.5 and sum = 2.4).
 #ifndef CH_BN_CHUNK
 #define CH_BN_CHUNK 8
 #endif
 #ifndef CH_BN_NLDS
 #define CH_BN_NLDS 0
 #endif
+#ifndef CH_BN_AHEAD
+#define CH_BN_AHEAD 2
+#endif
+#ifndef CH_BN_PREFETCH
+#define CH_BN_PREFETCH 1
+#endif
 template <int JAC, int CHUNK, int NLDS>
 __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
                                                               u8* __restrict__ inf, size_t n) {
+    // prefix[j] = product of the lane's non-zero z's before its point j, j = 1 .. CHUNK - 1 (prefix[0] = 1 is not kept):
+    // the first NLDS of them in LDS ([slot][limb][lane]), the others in registers
     __shared__ u64 s_prefix[(NLDS > 0 ? NLDS : 1) * 6 * BLOCK];
     const int t = threadIdx.x;
     const size_t tile_pts = (size_t)BLOCK * CHUNK;
     const size_t ntiles = (n + tile_pts - 1) / tile_pts;
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t e0 = tile * tile_pts + t;
-        Fp6 prefix[CHUNK > NLDS ? CHUNK - NLDS : 1];  // prefix[j - NLDS] = product of the lane's non-zero z's before its point j
+        Fp6 prefix[CHUNK - 1 > NLDS ? CHUNK - 1 - NLDS : 1];
         Fp6 acc = fp6_one();
-        Fp6 z_next = e0 < n ? load_fp6_vec(xyz + 18 * e0 + 12) : fp6_zero();
+        Fp6 zq[CH_BN_AHEAD];  // the z's of the next CH_BN_AHEAD points, requested that many steps before their use
+#pragma unroll
+        for (int d = 0; d < CH_BN_AHEAD; d++) {
+            const size_t en = e0 + (size_t)d * BLOCK;
+            zq[d] = (d < CHUNK && en < n) ? load_fp6_vec(xyz + 18 * en + 12) : fp6_zero();
+        }
 #pragma unroll
         for (int j = 0; j < CHUNK; j++) {
-            const Fp6 z = z_next;  // a point beyond n reads as z = 0: skipped like an identity, never stored
-            if (j + 1 < CHUNK) {
-                const size_t en = e0 + (size_t)(j + 1) * BLOCK;
-                z_next = en < n ? load_fp6_vec(xyz + 18 * en + 12) : fp6_zero();
+            const Fp6 z = zq[j % CH_BN_AHEAD];  // a point beyond n reads as z = 0: skipped like an identity, never stored
+            if (j + CH_BN_AHEAD < CHUNK) {
+                const size_t en = e0 + (size_t)(j + CH_BN_AHEAD) * BLOCK;
+                zq[j % CH_BN_AHEAD] = en < n ? load_fp6_vec(xyz + 18 * en + 12) : fp6_zero();
             }
-            if (j < NLDS) {
+            if (j >= 1 && j - 1 < NLDS) {
 #pragma unroll
-                for (int l = 0; l < 6; l++) s_prefix[(j * 6 + l) * BLOCK + t] = acc.c[l];
-            } else {
-                prefix[j - NLDS] = acc;
+                for (int l = 0; l < 6; l++) s_prefix[((j - 1) * 6 + l) * BLOCK + t] = acc.c[l];
+            } else if (j >= 1) {
+                prefix[j - 1 - NLDS] = acc;
             }
-            Fp6 m = fp6_mul(acc, z);
-            acc = fp6_select(m, acc, fp6_is_zero(z));
+            if (j == 0) {
+                acc = fp6_select(z, acc, fp6_is_zero(z));
+            } else {
+                Fp6 m = fp6_mul(acc, z);
+                acc = fp6_select(m, acc, fp6_is_zero(z));
+            }
         }
         bool some;
         acc = fp6_invert(acc, &some);
-        // backward pass, operands of point j - 1 requested while point j is computed
+        // backward pass; with CH_BN_PREFETCH the operands of point j - 1 are requested while point j is computed
         Fp6 nx, ny, nz;
-        {
+        if (CH_BN_PREFETCH) {
             const size_t e = e0 + (size_t)(CHUNK - 1) * BLOCK;
             const bool in = e < n;
             const u64* p = xyz + 18 * (in ? e : 0);
@@ -361,26 +385,42 @@ __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u6
 #pragma unroll
         for (int j = CHUNK - 1; j >= 0; j--) {
             const size_t e = e0 + (size_t)j * BLOCK;
-            const Fp6 x = nx, y = ny, z = nz;
-            if (j > 0) {
-                const size_t ep = e - BLOCK;
-                const bool in = ep < n;
-                const u64* p = xyz + 18 * (in ? ep : 0);
-                nx = load_fp6_vec(p);
-                ny = load_fp6_vec(p + 6);
-                nz = in ? load_fp6_vec(p + 12) : fp6_zero();
-            }
-            Fp6 pre;
-            if (j < NLDS) {
-#pragma unroll
-                for (int l = 0; l < 6; l++) pre.c[l] = s_prefix[(j * 6 + l) * BLOCK + t];
+            Fp6 x, y, z;
+            if (CH_BN_PREFETCH) {
+                x = nx;
+                y = ny;
+                z = nz;
+                if (j > 0) {
+                    const size_t ep = e - BLOCK;
+                    const bool in = ep < n;
+                    const u64* p = xyz + 18 * (in ? ep : 0);
+                    nx = load_fp6_vec(p);
+                    ny = load_fp6_vec(p + 6);
+                    nz = in ? load_fp6_vec(p + 12) : fp6_zero();
+                }
             } else {
-                pre = prefix[j - NLDS];
+                const bool in = e < n;
+                const u64* p = xyz + 18 * (in ? e : 0);
+                z = in ? load_fp6_vec(p + 12) : fp6_zero();
+                x = load_fp6_vec(p);
+                y = load_fp6_vec(p + 6);
             }
             const bool skip = fp6_is_zero(z);
-            Fp6 zi = fp6_mul(pre, acc);  // 1 / z_j
-            Fp6 m = fp6_mul(acc, z);
-            acc = fp6_select(m, acc, skip);
+            Fp6 zi;  // 1 / z_j
+            if (j == 0) {
+                zi = acc;
+            } else {
+                Fp6 pre;
+                if (j - 1 < NLDS) {
+#pragma unroll
+                    for (int l = 0; l < 6; l++) pre.c[l] = s_prefix[((j - 1) * 6 + l) * BLOCK + t];
+                } else {
+                    pre = prefix[j - 1 - NLDS];
+                }
+                zi = fp6_mul(pre, acc);
+                Fp6 m = fp6_mul(acc, z);
+                acc = fp6_select(m, acc, skip);
+            }
             Affine o;
             if (JAC) {
                 Fp6 zi2 = fp6_square(zi);
