@@ -54,6 +54,7 @@ struct cheetah_ctx {
     size_t scratch_words = 0;
     u64* noalloc_arena = nullptr;  // this device's address of noalloc_scratch (hipGetSymbolAddress, once, at creation)
     int num_cus = 0;
+    bool force_reference_schedule = false;  // cheetah_debug_set_reference_schedule: no composed fast paths
     int reserved_cus = 0;  // CUs' worth of workgroup slots the persistent launches leave free (cheetah_ctx_set_reserved_cus)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     // host-pointer pipeline: copy streams, per-buffer-set events, staging buffers (two sets)
@@ -62,6 +63,7 @@ struct cheetah_ctx {
     std::vector<DevSlot> stage[2];
     // multi-device: the caller's context is shard 0 and owns one sub-context per further device
     std::vector<cheetah_ctx*> subs;
+    DevSlot pair_tmp;           // multiply_double_with_basepoint_vartime, affine results: split scalars and the two partial points
     std::vector<DevSlot> peer;  // a sub-context's staging for `_dev` calls (its shard of the caller's device arrays)
     hipEvent_t ev_peer = nullptr;
     std::string err;
@@ -131,6 +133,7 @@ static void destroy_one(cheetah_ctx* ctx) {
             if (d.p) (void)hipFree(d.p);
     for (auto& d : ctx->peer)
         if (d.p) (void)hipFree(d.p);
+    if (ctx->pair_tmp.p) (void)hipFree(ctx->pair_tmp.p);
     hipEvent_t evs[] = {ctx->ev0, ctx->ev1, ctx->ev_order, ctx->ev_peer, ctx->ev_in[0], ctx->ev_in[1],
                         ctx->ev_k[0], ctx->ev_k[1], ctx->ev_out[0], ctx->ev_out[1]};
     for (hipEvent_t e : evs)
@@ -292,6 +295,13 @@ extern "C" int32_t cheetah_ctx_synchronize(cheetah_ctx* ctx) {
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CHEETAH_OK;
+}
+
+extern "C" int32_t cheetah_debug_set_reference_schedule(cheetah_ctx* ctx, int on) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    ctx->force_reference_schedule = on != 0;
+    for (cheetah_ctx* s : ctx->subs) s->force_reference_schedule = on != 0;
     return CHEETAH_OK;
 }
 
@@ -960,12 +970,62 @@ extern "C" int32_t cheetah_multiply_batch_dev_noalloc(cheetah_ctx* ctx, const ui
 
 // --------------------------------------------- multi-scalar ladders, checks -----
 
+static int ew_grid(const cheetah_ctx* c, size_t n) {
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)c->num_cus * 8;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+// multiply_double_with_basepoint_vartime with AFFINE results: out[i] = a_i P_i + b_i G as the sum of the two
+// single-scalar fast paths (fixed-window ladder with indexed lookups for a P, widened comb for b G) instead of the
+// reference's Straus NAF ladder: the affine point is the same for every pair of scalars below 2^255, and the waves
+// that hold a larger one are redone by the NAF kernel afterwards.  Sub-batches of 2^19 bound the temporaries (135 MB).
+static int32_t double_with_basepoint_affine(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars64, u64* out, u8* inf,
+                                            size_t n) {
+    constexpr size_t SUB = (size_t)1 << 19;
+    const size_t cap = n < SUB ? (n + 255) / 256 * 256 : SUB;
+    if (int32_t rc = ensure_slot(ctx, ctx->pair_tmp, cap * 258, ctx->stream)) return rc;
+    u8* base = static_cast<u8*>(ctx->pair_tmp.p);
+    u8* a32 = base;
+    u8* b32 = a32 + cap * 32;
+    u64* ap = reinterpret_cast<u64*>(b32 + cap * 32);
+    u64* bg = ap + cap * 12;
+    u8* ap_inf = reinterpret_cast<u8*>(bg + cap * 12);
+    u8* bg_inf = ap_inf + cap;
+    const size_t wpb = ManyScratch::words(1, 2);
+    const int grid_many = lane_grid(ctx, n < SUB ? n : SUB, CH_MANY_WAVES);
+    if (int32_t rc = ensure_scratch(ctx, (size_t)grid_many * wpb)) return rc;
+    const size_t in_w = form_limbs(in_form);
+    for (size_t off = 0; off < n; off += SUB) {
+        const size_t cnt = n - off < SUB ? n - off : SUB;
+        const u64* pts_o = pts + off * in_w;
+        const u8* sc_o = scalars64 + off * 64;
+        hipLaunchKernelGGL(k_split_scalar_pairs, dim3(ew_grid(ctx, cnt * 8)), dim3(BLOCK), 0, ctx->stream,
+                           reinterpret_cast<const u64*>(sc_o), reinterpret_cast<u64*>(a32), reinterpret_cast<u64*>(b32), cnt);
+        if (int32_t rc = multiply_impl<true>(ctx, pts_o, in_form, a32, ap, ap_inf, cnt, CHEETAH_AFFINE)) return rc;
+        if (int32_t rc = fixed_base_impl<false>(ctx, TAB(ctx, basepoint), TAB(ctx, wide), b32, bg, bg_inf, cnt, CHEETAH_AFFINE)) return rc;
+        hipLaunchKernelGGL(k_affine_sum, dim3(ew_grid(ctx, cnt)), dim3(BLOCK), 0, ctx->stream, ap, ap_inf, bg, bg_inf, out + off * 12,
+                           inf + off, cnt);
+#define FIXUP(I) \
+    hipLaunchKernelGGL((k_multiply_many_vartime<MJac, I, 0, true>), dim3(grid_many), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o, sc_o, \
+                       out + off * 12, inf + off, cnt, 1, 1, ctx->scratch, wpb)
+        if (in_form == CHEETAH_AFFINE) FIXUP(0);
+        else if (in_form == CHEETAH_PROJECTIVE) FIXUP(1);
+        else FIXUP(2);
+#undef FIXUP
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
 template <bool VARTIME>
 static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, int m, int with_basepoint,
                                   u64* out, u8* inf, size_t n_groups, int out_form) {
     SET_DEVICE(ctx);
     if (out_form == CHEETAH_AFFINE && !inf) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     if (!aligned8(pts) || !aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+    if constexpr (VARTIME)
+        if (with_basepoint && m == 1 && out_form == CHEETAH_AFFINE && !ctx->force_reference_schedule)
+            return double_with_basepoint_affine(ctx, pts, in_form, scalars32, out, inf, n_groups);
     const int ns = m + (with_basepoint ? 1 : 0);
     int grid = lane_grid(ctx, n_groups, CH_MANY_WAVES);
     const size_t wpb = ManyScratch::words(m, ns);
@@ -982,6 +1042,15 @@ static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form,
         u8* inf_o = inf ? inf + off : nullptr;
 #define LAUNCH(A, I, O)                                                                                                           \
     do {                                                                                                                          \
+        if constexpr (VARTIME && O == 0) {                                                                                        \
+            if (!with_basepoint && !ctx->force_reference_schedule) { /* affine results: indexed fixed-window ladder + fix-up */    \
+                hipLaunchKernelGGL((k_multiply_many_ct<MJac, I, 0, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,   \
+                                   pts_o, sc_o, out_o, inf_o, cnt, m, ctx->scratch, wpb);                                         \
+                hipLaunchKernelGGL((k_multiply_many_vartime<MJac, I, 0, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream,           \
+                                   ctx->tables, pts_o, sc_o, out_o, inf_o, cnt, m, 0, ctx->scratch, wpb);                         \
+                break;                                                                                                            \
+            }                                                                                                                     \
+        }                                                                                                                         \
         if (VARTIME)                                                                                                              \
             hipLaunchKernelGGL((k_multiply_many_vartime<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,    \
                                sc_o, out_o, inf_o, cnt, m, with_basepoint, ctx->scratch, wpb);                                    \
@@ -1128,11 +1197,6 @@ extern "C" int32_t cheetah_clear_cofactor_batch_dev(cheetah_ctx* ctx, const uint
 extern "C" int32_t cheetah_clear_cofactor_batch(cheetah_ctx* ctx, const uint64_t* pts, int in_form, uint64_t* out, uint8_t* inf,
                                                 size_t n, int out_form) {
     return clear_cofactor_op(ctx, true, pts, in_form, out, inf, n, out_form);
-}
-
-static int ew_grid(const cheetah_ctx* c, size_t n) {
-    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)c->num_cus * 8;
-    return (int)(tiles < cap ? tiles : cap);
 }
 
 static int32_t is_on_curve_op(cheetah_ctx* ctx, bool host, const u64* pts, int in_form, u8* flags, size_t n) {

@@ -885,7 +885,13 @@ CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* 
 
 // LookupTable<N>::from for the lane's input point: the shared-inversion affine construction, and for a wave that holds
 // an exceptional point the reference's own construction.  Returns the identity mask of the entries.
-template <int IN_FORM>
+// NAF_IDENTITY (the vartime entry points' fixed-window fast path): a ProjectivePoint (X, Y, 0) with X != 0 is an
+// identity to the reference (is_identity() is z == 0, and its unchecked formulas do return such representatives), but
+// it is not a point of the curve, so the complete additions that fill LookupTable<N> turn its "multiples" into
+// arbitrary values: the reference's multiply() really returns those (and so does the constant-time path here), while
+// its multiply_vartime() returns the identity -- every entry of its NafLookupTable stays at z = 0.  With NAF_IDENTITY
+// such an input is replaced by (0, 1, 0), whose table is all identities, so the fast path agrees with the NAF ladder.
+template <int IN_FORM, bool NAF_IDENTITY = false>
 CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
     Affine pa;
     if (IN_FORM == 1) {
@@ -897,7 +903,11 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
         pa.inf = fp6_is_zero(p.z);
     }
     const bool ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t);
-    if (__any(!ok)) return build_table<false>(load_input_point<IN_FORM>(pts, i), n_entries, s_tab, s_z, s_prefix, t);
+    if (__any(!ok)) {
+        Proj p = load_input_point<IN_FORM>(pts, i);
+        if (IN_FORM == 1 && NAF_IDENTITY && fp6_is_zero(p.z)) p = proj_identity();
+        return build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
+    }
     return 0u;
 }
 
@@ -981,7 +991,7 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
         const bool wide = (k[3] >> 60) > 7;
         if (DIRECT && __any((int)(k[3] >> 63))) continue;  // this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
-        const u32 ident = build_lookup_table<IN_FORM>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_lookup_table<IN_FORM, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
         const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
@@ -1075,7 +1085,10 @@ struct ManyScratch {
     static size_t words(int m, int ns) { return (size_t)m * TAB + 2 * ZP + (size_t)m * BLOCK + (size_t)ns * 256 * BLOCK / 8; }
 };
 
-template <class ACC, int IN_FORM, int OUT_FORM>
+// DIRECT (variable time, affine results only): table entries read by index -- the fast path of multiply_many_vartime /
+// multiply_double_vartime, whose affine result is this ladder's for scalars below 2^255; a wave that holds a larger one
+// is left to k_multiply_many_vartime<..., ONLY_WIDE>.
+template <class ACC, int IN_FORM, int OUT_FORM, bool DIRECT = false>
 __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                             const u8* __restrict__ scalars, u64* __restrict__ out,
                                                             u8* __restrict__ inf, size_t n_groups, int m,
@@ -1099,9 +1112,10 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
             recode_radix16(k, s_dig + (size_t)j * 256 * BLOCK, t);
             wide = wide || (k[3] >> 60) > 7;
         }
+        if (DIRECT && __any(wide)) continue;  // top nibble > 7 <=> bit 255 set: this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
         for (int j = 0; j < m; j++) {
-            s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
+            s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, DIRECT>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
         }
         ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S
         for (int w = 63; w >= 0; w--) {
@@ -1110,8 +1124,9 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
                 acc = Ladder<ACC>::dbl_then_add(acc);
             }
             for (int j = 0; j < m; j++) {
-                const Affine q = scan_lookup(s_tabs + (size_t)j * ManyScratch::TAB, n_entries, s_ident[j * BLOCK + t],
-                                             s_dig[((size_t)j * 256 + w) * BLOCK + t], t);
+                const int d = s_dig[((size_t)j * 256 + w) * BLOCK + t];
+                const u64* tb = s_tabs + (size_t)j * ManyScratch::TAB;
+                const Affine q = DIRECT ? index_lookup(tb, s_ident[j * BLOCK + t], d, t) : scan_lookup(tb, n_entries, s_ident[j * BLOCK + t], d, t);
                 acc = (j == 0 && w < 63) ? Ladder<ACC>::add_after_dbl(acc, q) : Ladder<ACC>::add(acc, q);
             }
         }
@@ -1120,7 +1135,9 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
     }
 }
 
-template <class ACC, int IN_FORM, int OUT_FORM>
+// ONLY_WIDE: run only the waves that hold a scalar with bit 255 set (no canonical scalar has it); the others were
+// done by the composed path of multiply_double_with_basepoint_vartime (k_affine_sum below).
+template <class ACC, int IN_FORM, int OUT_FORM, bool ONLY_WIDE = false>
 __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(const DeviceTables* __restrict__ tab,
                                                                  const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                                  u64* __restrict__ out, u8* __restrict__ inf, size_t n_groups,
@@ -1140,6 +1157,11 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
         const size_t g = round * BLOCK + t;
         const bool active = g < n_groups;
         const size_t gg = active ? g : n_groups - 1;
+        if (ONLY_WIDE) {
+            int wide = 0;
+            for (int j = 0; j < ns; j++) wide |= (int)(scalars[(gg * ns + j) * 32 + 31] >> 7);
+            if (!__any(wide)) continue;
+        }
         for (int j = 0; j < ns; j++) {
             u64 k[4];
             load_scalar(scalars, gg * ns + j, k);
@@ -1200,6 +1222,34 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
     }
 }
 
+
+// multiply_double_with_basepoint_vartime with affine results, composed (capi.hip): the scalar pairs are split,
+// a P runs through the fixed-window ladder (k_multiply_ct<..., DIRECT>), b G through the widened comb
+// (k_mul_by_generator_wide), and the two affine points are added here with the complete formula and normalised.
+// The sum is the affine point the reference's Straus ladder returns (src/curve/projective.rs:756-809,
+// src/curve/jacobian.rs:745-799) for every pair of scalars below 2^255; waves with a larger one are redone by
+// k_multiply_many_vartime<..., ONLY_WIDE>.
+__global__ void __launch_bounds__(BLOCK) k_split_scalar_pairs(const u64* __restrict__ pairs, u64* __restrict__ first,
+                                                              u64* __restrict__ second, size_t n) {
+    for (size_t w = (size_t)blockIdx.x * BLOCK + threadIdx.x; w < n * 8; w += (size_t)gridDim.x * BLOCK) {
+        const size_t i = w >> 3, l = w & 7;
+        const u64 v = pairs[w];
+        if (l < 4) first[4 * i + l] = v;
+        else second[4 * i + l - 4] = v;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_affine_sum(const u64* __restrict__ a_xy, const u8* __restrict__ a_inf,
+                                                      const u64* __restrict__ b_xy, const u8* __restrict__ b_inf,
+                                                      u64* __restrict__ out, u8* __restrict__ inf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Affine a = load_affine(a_xy + 12 * i), b = load_affine(b_xy + 12 * i);
+        a.inf = a_inf[i] != 0;
+        b.inf = b_inf[i] != 0;
+        Proj r = jac_add_mixed(proj_from_affine(a), b);  // (x, y, 1) is a's Jacobian form too
+        if (a.inf) r = proj_from_affine(b);              // the one case add_mixed does not select (quirk Q6)
+        store_affine(out, inf, i, affine_from_jac(r));
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Point encodings (src/curve/encoding.rs): 97-byte uncompressed and 49-byte

@@ -484,6 +484,11 @@ class Engine:
         another stream); 0 = none."""
         self._check(self._lib.cheetah_ctx_set_reserved_cus(self._h, int(cus)))
 
+    def set_reference_schedule(self, on):
+        """Tests / tools: run multiply_double_with_basepoint_vartime's affine results by the reference's Straus NAF
+        schedule instead of the composed one (same results)."""
+        self._check(self._lib.cheetah_debug_set_reference_schedule(self._h, int(bool(on))))
+
     def multiply_units_per_launch(self, n, vartime=False, out_form=AFFINE):
         """Scalar multiplications per kernel launch for a batch of n (the library bounds each launch)."""
         v = C.c_size_t()

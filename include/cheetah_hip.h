@@ -319,6 +319,10 @@ int32_t cheetah_debug_op_dev(cheetah_ctx *ctx, int op, const uint64_t *a, const 
 /* A multi-shard context whose n_shards shards all live on ONE device: the sharding, peer-copy and gather paths of a
  * multi-device context on a one-GPU box (tests only; cheetah_ctx_create itself rejects a device listed twice). */
 int32_t cheetah_debug_ctx_create_replicated(int device_id, int n_shards, cheetah_ctx **out);
+/* on != 0: multiply_double_with_basepoint_vartime with AFFINE results runs the reference's Straus NAF schedule
+ * (k_multiply_many_vartime) instead of the composed one (a P by the fixed-window ladder + b G by the widened comb + one
+ * complete addition).  The affine results are the same; tests and tools compare and time the two. */
+int32_t cheetah_debug_set_reference_schedule(cheetah_ctx *ctx, int on);
 /* Measured v_mad_u64_u32 issue rate of this device in 1e12 lane-ops/s (roofline denominator). */
 int32_t cheetah_calibrate_mad_peak(cheetah_ctx *ctx, double *tera_mads_per_s);
 /* How many scalar multiplications one kernel launch of cheetah_multiply_batch_dev (vartime = 0) or

@@ -169,6 +169,21 @@ def _random_points(ora, seed, n, form):
     return out
 
 
+def _to_form(ora, aff, form, seed):
+    """Given affine points ((0, 1) = identity) -> projective (x l, y l, l) / Jacobian (x l^2, y l^3, l) representatives."""
+    n = len(aff)
+    lam = synth.fp6_elements(seed, n).reshape(n, 6)
+    x, y = np.ascontiguousarray(aff[:, :6]), np.ascontiguousarray(aff[:, 6:])
+    if form == "jac":
+        l2 = ora.fp6_square_batch(lam).reshape(n, 6)
+        out = np.concatenate([ora.fp6_mul_batch(x, l2).reshape(n, 6), ora.fp6_mul_batch(y, ora.fp6_mul_batch(l2, lam).reshape(n, 6)).reshape(n, 6), lam], axis=1)
+    else:
+        out = np.concatenate([ora.fp6_mul_batch(x, lam).reshape(n, 6), ora.fp6_mul_batch(y, lam).reshape(n, 6), lam], axis=1)
+    ident = (aff[:, :6] == 0).all(axis=1) & (aff[:, 6] == 1) & (aff[:, 7:] == 0).all(axis=1)
+    out[ident, 12:] = 0
+    return np.ascontiguousarray(out)
+
+
 def test_point_formulas_projective_parity(eng, ora):
     """double_unchecked / add / add_mixed_unchecked give the reference's own
     (X:Y:Z) representative (parity level L2), src/curve/projective.rs:400-610."""
@@ -472,6 +487,11 @@ def test_multiply_vs_oracle_all_forms(eng, ora, n):
     jac = _random_points(ora, 81, n, "jac")
     if n >= 64:
         jac[20, 12:18] = 0                      # Jacobian identity
+    if n >= 300:                                # the same in a wave without a wide scalar (multiply_vartime's AFFINE results take the
+        aff[100] = [0] * 6 + [1] + [0] * 5      # fixed-window path there): (X, Y, 0) with X != 0 is an identity whose LookupTable
+        prj[100, 12:18] = 0                     # entries are arbitrary values and whose NafLookupTable entries are identities
+        jac[100, 12:18] = 0
+        prj[101] = [0] * 6 + [1] + [0] * 5 + [0] * 6
     for vartime in (False, True):
         f = eng.multiply_vartime_batch if vartime else eng.multiply_batch
         for in_form, pts in ((AFFINE, aff), (PROJECTIVE, prj)):
@@ -594,6 +614,10 @@ def test_multiply_many_vs_oracle(eng, ora, m):
     edge = [0, 1, Q - 1, 16, (1 << 255) - 1]
     for i, k in enumerate(edge):
         sc[i] = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    # bit 255 set (no canonical scalar): the radix-16 and NAF ladders differ there; the vartime entry points'
+    # affine fast path must hand those waves to the NAF kernel
+    sc[n * m - 3] = np.frombuffer(int((1 << 255) + 77).to_bytes(32, "little"), np.uint8)
+    sc[n * m - 1] = np.frombuffer(int((1 << 256) - 1).to_bytes(32, "little"), np.uint8)
     aff = _random_points(ora, 83, n * m, "affine")
     prj = _random_points(ora, 83, n * m, "proj")
     jac = _random_points(ora, 83, n * m, "jac")
@@ -643,6 +667,57 @@ def test_multiply_double_with_basepoint_vartime(eng, ora):
     got, inf = eng.multiply_double_with_basepoint_vartime_batch(aff, sc, AFFINE, AFFINE)
     want, winf = ora.multiply_many_batch(aff, 0, sc, 1, 0, vartime=True, with_basepoint=True)
     assert (got == want).all() and (inf == winf).all()
+
+
+def test_multiply_double_with_basepoint_composed_path(eng, ora, kats):
+    """The AFFINE results of multiply_double_with_basepoint_vartime come from a composed schedule (a P by the
+    fixed-window ladder, b G by the widened comb, one complete addition, k_affine_sum): against the oracle's restatement
+    of the reference's Straus ladder on the cases the final addition selects on (a P = b G, a P = -b G, either or both the
+    identity, P the identity), with scalars that have bit 255 set in either position (those waves are redone by the NAF
+    kernel), for the three input forms; and against the reference schedule on the GPU at 2^18."""
+    import torch
+    from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE
+    n = 600
+    le = lambda k: np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    sc = synth.scalars(18, 2 * n).reshape(n, 2, 32)
+    aff = _random_points(ora, 95, n, "affine")
+    g = np.array(kats["generator"]["x"] + kats["generator"]["y"], np.uint64)
+    neg_g = g.copy()
+    neg_g[6:] = (np.uint64(P) - g[6:]) % np.uint64(P)
+    ident = np.array([0] * 6 + [1] + [0] * 5, np.uint64)
+    cases = [(g, 5, 5), (g, 5, Q - 5), (neg_g, 7, 7), (neg_g, 9, Q - 9), (g, 0, 0), (g, 0, 11), (g, 11, 0), (ident, 3, 4),
+             (ident, 3, 0), (g, Q - 1, 1), (g, 1, Q - 1), (g, (1 << 255) - 1, 2)]
+    for i, (pt, a, b) in enumerate(cases):
+        j = 64 + 3 * i                       # in waves that hold no wide scalar
+        aff[j] = pt
+        sc[j, 0], sc[j, 1] = le(a), le(b)
+    wide = [((1 << 255) + 12345, 7), (7, (1 << 255) + 99), ((1 << 256) - 1, (1 << 256) - 1), (1 << 255, 1 << 255)]
+    for i, (a, b) in enumerate(wide):        # waves 4.. of the batch: redone by the NAF kernel, neighbours included
+        j = 256 + 64 * i + 5
+        sc[j, 0], sc[j, 1] = le(a), le(b)
+    sc = np.ascontiguousarray(sc.reshape(2 * n, 32))
+    prj = _to_form(ora, aff, "proj", 96)
+    jac = _to_form(ora, aff, "jac", 96)
+    for in_form, pts in ((AFFINE, aff), (PROJECTIVE, prj), (JACOBIAN, jac)):
+        want, winf = ora.multiply_many_batch(pts, in_form, sc, 1, AFFINE, vartime=True, with_basepoint=True)
+        got, inf = eng.multiply_double_with_basepoint_vartime_batch(dev(pts), dev(sc), in_form, AFFINE)
+        assert (host(got) == want).all() and (host(inf) == winf).all(), in_form
+        got, inf = eng.multiply_double_with_basepoint_vartime_batch(pts, sc, in_form, AFFINE)
+        assert (got == want).all() and (inf == winf).all(), in_form
+    # the selections did what they are for
+    j = 64
+    assert winf[j + 3] == 1 and winf[j + 6] == 1 and winf[j + 12] == 1     # 5G - 5G, -7G + 7G, 0 + 0
+    # 2^18 pairs: composed == reference schedule
+    N = 1 << 18
+    k = eng.synth_scalars(19, 2 * N)
+    pts, _ = eng.mul_by_generator_batch(eng.synth_scalars(20, N), AFFINE)
+    a, ai = eng.multiply_double_with_basepoint_vartime_batch(pts, k, AFFINE, AFFINE)
+    eng.set_reference_schedule(True)
+    try:
+        b, bi = eng.multiply_double_with_basepoint_vartime_batch(pts, k, AFFINE, AFFINE)
+    finally:
+        eng.set_reference_schedule(False)
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and torch.equal(ai, bi)
 
 
 def test_is_torsion_free_and_clear_cofactor(eng, ora, kats):

@@ -22,10 +22,13 @@ for m in (2, 4):
         print("%-24s m=%d 2^%d groups: %9.3f ms  %7.3f M groups/s  %7.3f M scalar mults/s" % (name, m, lg, best, g / best / 1e3, n / best / 1e3), flush=True)
 k2 = eng.synth_scalars(8, 2 << lg, 0)
 p1, _ = eng.mul_by_generator_batch(eng.synth_scalars(8, 1 << lg, 1 << 26), AFFINE)
-best = 1e30
-for _ in range(2):
-    eng._use_torch_stream(); eng.timer_start()
-    out = eng.multiply_double_with_basepoint_vartime_batch(p1, k2, AFFINE, AFFINE)
-    best = min(best, eng.timer_stop_ms())
-print("%-24s     2^%d groups: %9.3f ms  %7.3f M groups/s" % ("double_with_basepoint_vt", lg, best, (1 << lg) / best / 1e3), flush=True)
+for ref in (True, False):  # the reference's Straus NAF schedule, then the composed one (a P + b G + one addition)
+    eng.set_reference_schedule(ref)
+    best = 1e30
+    for _ in range(3):
+        eng._use_torch_stream(); eng.timer_start()
+        out = eng.multiply_double_with_basepoint_vartime_batch(p1, k2, AFFINE, AFFINE)
+        best = min(best, eng.timer_stop_ms())
+    print("%-24s     2^%d groups: %9.3f ms  %7.3f M groups/s  (%s)" % ("double_with_basepoint_vt", lg, best, (1 << lg) / best / 1e3,
+                                                                      "Straus NAF kernel" if ref else "composed"), flush=True)
 eng.close()
