@@ -142,9 +142,19 @@ def test_sharded_context_equals_single_device_host_arrays(eng, eng3, n):
         assert (dxy == xy).all() and (dinf == inf).all() and dsome.all()
     assert (eng3.is_torsion_free_batch(pts, AFFINE) == 1).all()
     if n >= 2 and n % 2 == 0:
-        m3, mi3 = eng3.multiply_many_batch(pts, k, 2, AFFINE, AFFINE)
-        m1, mi1 = eng.multiply_many_batch(pts, k, 2, AFFINE, AFFINE)
-        assert (m3 == m1).all() and (mi3 == mi1).all()
+        for f in ("multiply_many_batch", "multiply_many_vartime_batch"):
+            m3, mi3 = getattr(eng3, f)(pts, k, 2, AFFINE, AFFINE)
+            m1, mi1 = getattr(eng, f)(pts, k, 2, AFFINE, AFFINE)
+            assert (m3 == m1).all() and (mi3 == mi1).all(), f
+    # group law and the composed a P + b G path (its temporaries live in each shard's context)
+    dbl = eng.double_batch(jac, JACOBIAN)
+    assert (eng3.double_batch(jac, JACOBIAN) == dbl).all()
+    assert (eng3.add_batch(jac, dbl, JACOBIAN) == eng.add_batch(jac, dbl, JACOBIAN)).all()
+    assert (eng3.add_batch(jac, pts, JACOBIAN, AFFINE) == eng.add_batch(jac, pts, JACOBIAN, AFFINE)).all()
+    k2 = synth.scalars(15, 2 * n)
+    d3, di3 = eng3.multiply_double_with_basepoint_vartime_batch(pts, k2, AFFINE, AFFINE)
+    d1, di1 = eng.multiply_double_with_basepoint_vartime_batch(pts, k2, AFFINE, AFFINE)
+    assert (d3 == d1).all() and (di3 == di1).all()
 
 
 @pytest.mark.parametrize("n", [3, 1000, 2049])
@@ -169,6 +179,12 @@ def test_sharded_context_equals_single_device_device_arrays(eng, eng3, n):
     assert torch.equal(x3[0].view(torch.int64), y3[0].view(torch.int64)) and torch.equal(x3[1], y3[1])
     e3, e1 = eng3.to_uncompressed_batch(*y3), eng.to_uncompressed_batch(*y3)
     assert torch.equal(e3, e1)
+    s3, s1 = eng3.add_batch(r3, pts, PROJECTIVE, AFFINE), eng.add_batch(r3, pts, PROJECTIVE, AFFINE)
+    assert torch.equal(s3.view(torch.int64), s1.view(torch.int64))
+    k2 = dev(synth.scalars(25, 2 * n))
+    d3, di3 = eng3.multiply_double_with_basepoint_vartime_batch(pts, k2, AFFINE, AFFINE)
+    d1, di1 = eng.multiply_double_with_basepoint_vartime_batch(pts, k2, AFFINE, AFFINE)
+    assert torch.equal(d3.view(torch.int64), d1.view(torch.int64)) and torch.equal(di3, di1)
     torch.cuda.synchronize()
 
 
