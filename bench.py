@@ -87,6 +87,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the Fp6 / batch_normalize roofline measurements")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="CUs' worth of workgroup slots the persistent launches leave free for the RCCL kernel (--gpus > 1)")
+    ap.add_argument("--rccl-at-one", action="store_true",
+                    help="--gpus 1 only: run the multi-GPU code path (NCCL process group with its options, chunked in-place "
+                         "all-gathers from the side stream, all-reduces) in a one-rank group -- execution evidence for that "
+                         "path on a one-GPU box, not a scaling measurement")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="gloo on CPU with a stand-in for the arithmetic: launcher / sharding / gather rehearsal, not a measurement")
     return ap.parse_args()
@@ -287,23 +291,27 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     import torch.distributed as dist
-    if world > 1:
+    dist_on = world > 1 or args.rccl_at_one
+    if dist_on:
+        kw = {}
+        if world == 1:  # --rccl-at-one: no launcher set the rendezvous up
+            kw = {"init_method": "tcp://127.0.0.1:%d" % _free_port(), "rank": 0, "world_size": 1}
         # the collective's kernel runs on ProcessGroupNCCL's own stream: ask for that one to be high priority
         try:
             opts = dist.ProcessGroupNCCL.Options()
             opts.is_high_priority_stream = True
-            dist.init_process_group("nccl", device_id=torch.device(device), pg_options=opts)
+            dist.init_process_group("nccl", device_id=torch.device(device), pg_options=opts, **kw)
         except (AttributeError, TypeError, ValueError):
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            dist.init_process_group("nccl", device_id=torch.device(device), **kw)
 
     from cheetah_amd import AFFINE, Engine
     from cheetah_amd.distributed import shard_plan, sharded_apply
 
     eng = Engine(local_rank)
-    if world > 1 and args.reserve_cus:
+    if dist_on and args.reserve_cus:
         eng.set_reserved_cus(args.reserve_cus)
     n = 1 << args.log2n
-    chunks = args.chunks or (1 if world == 1 else 8)
+    chunks = args.chunks or (8 if dist_on else 1)
     s, plan = shard_plan(n, world, chunks)
 
     # ---- inputs, resident in HBM before the timed region ---------------------
@@ -324,7 +332,7 @@ def main():
         eng.multiply_batch(pts[j * s:(j + 1) * s], ks[j * s:(j + 1) * s], AFFINE, AFFINE, out=oxy, inf=oinf)
 
     def step(gather=True):
-        return sharded_apply(compute, n, 12, rank, world, chunks, device, gather=gather)
+        return sharded_apply(compute, n, 12, rank, world, chunks, device, gather=gather, collective_at_one=args.rccl_at_one)
 
     def timed_kernel_pass():
         # one un-overlapped pass, HIP events on the launch stream around each call's kernel launches
@@ -341,12 +349,12 @@ def main():
         return total / launches, chunks * s / launches, launches
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(v):
-        if world == 1:
+        if not dist_on:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -369,7 +377,7 @@ def main():
     # ---- what the gather costs: the same pass without it (this rank's blocks only) --------
     ones = torch.ones(1, dtype=torch.int64, device=device)
     compute_ms = None
-    if world > 1:
+    if dist_on:
         dist.all_reduce(ones)                     # ranks_seen: a sum of ones over RCCL
         barrier()
         t0 = time.perf_counter()
@@ -415,7 +423,7 @@ def main():
             "config": {"workload": "2^%d variable-base constant-time scalar mults (AffinePoint::multiply = JacobianPoint::multiply ladder), affine in/out, "
                                    "sharded over %d GPU(s), RCCL all-gather of results (BASELINE config 5)" % (args.log2n, world),
                        "n": n, "per_gpu": n // world, "allgather_chunks": chunks, "parallelism": "shard%d" % world,
-                       "reserved_cus": args.reserve_cus if world > 1 else 0},
+                       "reserved_cus": args.reserve_cus if dist_on else 0},
             "checksum": "%016x" % checksum,
             "identities": n_inf,
             "ranks_seen": int(ones.item()),
@@ -433,6 +441,8 @@ def main():
                                  "traffic = (FETCH_SIZE + WRITE_SIZE) per unit from the rocprofv3 PMC passes in profiles/ x units_per_launch: "
                                  "the lane's window table is re-read in each of the 64 windows (algorithmic bytes: 225 per unit)"},
         }
+        if args.rccl_at_one:
+            line["rccl_at_one"] = True
         if compute_ms is not None:
             line["compute_ms"] = compute_ms
             line["gather_ms_exposed"] = dt / args.steps * 1e3 - compute_ms
@@ -443,7 +453,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline((1 << args.cpu_sample_log2) * max(1, cores))
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -38,24 +38,28 @@ def shard_plan(n, world, chunks):
     return s, [[(c, c * per_chunk + r * s) for c in range(chunks)] for r in range(world)]
 
 
-def sharded_apply(compute, n, width, rank, world, chunks, device, dtype=torch.int64, group=None, gather=True):
+def sharded_apply(compute, n, width, rank, world, chunks, device, dtype=torch.int64, group=None, gather=True,
+                  collective_at_one=False):
     """Runs compute(global_start, count, out_xy_view, out_inf_view) for this rank's
     blocks and all-gathers the results.  Returns (xy, inf) holding all n results
     on every rank (gather=True), or with only this rank's blocks filled in.
 
     compute must enqueue its work on the CURRENT stream of `device`.
+    collective_at_one: issue the collectives even in a one-rank group (bench.py --rccl-at-one: the
+    RCCL code path on a one-GPU box).
     """
     s, plan = shard_plan(n, world, chunks)
     per_chunk = n // chunks
     xy = torch.empty((n, width), dtype=dtype, device=device)
     inf = torch.empty((n,), dtype=torch.uint8, device=device)
     use_cuda = torch.device(device).type == "cuda"
+    collective = gather and (world > 1 or collective_at_one)
     # a side stream orders "gather chunk c after its compute" without holding back chunk c + 1's launches
-    comm = torch.cuda.Stream(device=device) if (use_cuda and world > 1 and gather) else None
+    comm = torch.cuda.Stream(device=device) if (use_cuda and collective) else None
     main = torch.cuda.current_stream(device) if use_cuda else None
     for c, g0 in plan[rank]:
         compute(g0, s, xy[g0:g0 + s], inf[g0:g0 + s])
-        if world > 1 and gather:
+        if collective:
             lo = c * per_chunk
             if comm is not None:
                 comm.wait_stream(main)
