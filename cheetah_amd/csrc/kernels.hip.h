@@ -255,6 +255,11 @@ enum { EW_MUL = 0, EW_SQUARE = 1, EW_INVERT = 2, EW_SQRT = 3 };
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 CH_DEV Fp6 load_fp6_vec(const u64* p) {  // p is 16-byte aligned
+#ifdef CH_BN_NOMEM  // experiment: no memory reads at all, values derived from the address
+    Fp6 f;
+    for (int i = 0; i < 6; i++) f.c[i] = (u64)(size_t)p * 0x9E3779B97F4A7C15ull + i;
+    return f;
+#endif
     const u64x2* q = reinterpret_cast<const u64x2*>(p);
     u64x2 v0 = q[0], v1 = q[1], v2 = q[2];
     Fp6 r;
@@ -262,6 +267,10 @@ CH_DEV Fp6 load_fp6_vec(const u64* p) {  // p is 16-byte aligned
     return r;
 }
 CH_DEV void store_fp6_vec_canonical(u64* p, const Fp6& a) {
+#ifdef CH_BN_NOMEM
+    if (a.c[0] == 0x1234567 && a.c[3] == 0x7654321) p[0] = a.c[1];  // practically never: keeps the value alive
+    return;
+#endif
     u64x2* q = reinterpret_cast<u64x2*>(p);
     u64x2 v0, v1, v2;
     v0.x = fp_canonical(a.c[0]); v0.y = fp_canonical(a.c[1]);
@@ -318,7 +327,8 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
 // shows why: moving the records with no arithmetic at all takes 0.87 ms in this access pattern (0.77 ms with
 // wave-contiguous accesses), the VALU work alone is ~1.5 ms at the ladder kernels' issue rate, and the kernel needs
 // 70 % of the memory pipeline's capacity while it computes -- the two overlap, but not perfectly (2.1 ms lies between
-// max = 1.5 and sum = 2.4).
+// max = 1.5 and sum = 2.4).  The arithmetic alone, measured with -DCH_BN_NOMEM (no loads, stores elided), takes 1.80 ms at
+// this shape and 1.75 ms at (4, 3, 4): the kernel runs at 86 % of its own compute floor, whatever the occupancy.
 #ifndef CH_BN_CHUNK
 #define CH_BN_CHUNK 8
 #endif
