@@ -204,7 +204,12 @@ int32_t cheetah_multiply_batch_dev_noalloc(cheetah_ctx *ctx, const uint64_t *pts
  *                                      out[i] = s[2i] * pts[i] + s[2i+1] * G through ODD_MULTIPLES_BASEPOINT with a
  *                                      width-8 NAF (src/curve/projective.rs:756-809, src/curve/jacobian.rs:745-799)
  * Forms select Projective / Jacobian as for cheetah_multiply_batch (AffinePoint's wrappers give the same
- * affine point whichever ladder runs, src/curve/affine.rs:388-452).  1 <= m <= CHEETAH_MAX_MANY. */
+ * affine point whichever ladder runs, src/curve/affine.rs:388-452).  1 <= m <= CHEETAH_MAX_MANY.
+ * With an AFFINE out_form (level L1: the affine point, which no schedule can change) the two vartime entry points do
+ * not run the NAF schedule: multiply_many_vartime runs the fixed-window Straus ladder with table entries read by
+ * index, and multiply_double_with_basepoint_vartime is a * P by the fixed-window ladder plus b * G by the widened comb
+ * plus one complete addition.  Scalars with bit 255 set (no canonical scalar has it; the reference's NAF recoding
+ * truncates there) are detected per wave of 64 consecutive elements and those waves take the reference's schedule. */
 #define CHEETAH_MAX_MANY 64
 int32_t cheetah_multiply_many_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32, int m,
                                     uint64_t *out, uint8_t *inf, size_t n_groups, int out_form);

@@ -718,6 +718,18 @@ def test_multiply_double_with_basepoint_composed_path(eng, ora, kats):
     finally:
         eng.set_reference_schedule(False)
     assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and torch.equal(ai, bi)
+    # multiply_many_vartime, m = 2 and 3: the indexed fixed-window ladder == the NAF ladder on canonical scalars
+    for m in (2, 3):
+        G = N // 4
+        km = eng.synth_scalars(21 + m, G * m)
+        pm = pts[: G * m]
+        a, ai = eng.multiply_many_vartime_batch(pm, km, m, AFFINE, AFFINE)
+        eng.set_reference_schedule(True)
+        try:
+            b, bi = eng.multiply_many_vartime_batch(pm, km, m, AFFINE, AFFINE)
+        finally:
+            eng.set_reference_schedule(False)
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and torch.equal(ai, bi), m
 
 
 def test_is_torsion_free_and_clear_cofactor(eng, ora, kats):
