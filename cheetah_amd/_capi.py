@@ -32,6 +32,12 @@ SIGNATURES = {
     "cheetah_add_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _sz]),
     "cheetah_double_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_double_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_double_multi_batch": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
+    "cheetah_double_multi_batch_dev": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
+    "cheetah_neg_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_neg_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
+    "cheetah_eq_batch": (C.c_int32, [_vp, _vp, _vp, _i, _vp, _sz]),
+    "cheetah_eq_batch_dev": (C.c_int32, [_vp, _vp, _vp, _i, _vp, _sz]),
     "cheetah_is_on_curve_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_ctx_destroy": (C.c_int32, [_vp]),
     "cheetah_ctx_set_stream": (C.c_int32, [_vp, _vp]),

@@ -1405,21 +1405,61 @@ static int32_t add_op(cheetah_ctx* ctx, bool host, const u64* lhs, int lhs_form,
     };
     return run_op(ctx, host, op);
 }
-static int32_t double_op(cheetah_ctx* ctx, bool host, const u64* pts, int form, u64* out, size_t n) {
+static int32_t double_op(cheetah_ctx* ctx, bool host, const u64* pts, int form, u32 k, u64* out, size_t n) {
     if (!ctx) return CHEETAH_ERR_INVALID;
     if (form != CHEETAH_PROJECTIVE && form != CHEETAH_JACOBIAN)
         return fail(ctx, CHEETAH_ERR_INVALID, "form must be CHEETAH_PROJECTIVE or CHEETAH_JACOBIAN");
+    if (k < 1) return fail(ctx, CHEETAH_ERR_INVALID, "double_multi needs at least one doubling (the reference asserts n >= 1)");
     Op op;
     op.n = n;
     op.io = {in_(pts, 18 * 8), out_(out, 18 * 8)};
-    op.launch = [form](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+    op.launch = [form, k](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
         SET_DEVICE(c);
         if (!aligned8(d[0]) || !aligned8(d[1])) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
         const int grid = ew_grid(c, cnt);
         if (form == CHEETAH_PROJECTIVE)
-            hipLaunchKernelGGL((k_double<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt);
+            hipLaunchKernelGGL((k_double<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt, k);
         else
-            hipLaunchKernelGGL((k_double<2>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt);
+            hipLaunchKernelGGL((k_double<2>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt, k);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
+static int32_t neg_op(cheetah_ctx* ctx, bool host, const u64* pts, int form, u64* out, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, form, form)) return rc;
+    Op op;
+    op.n = n;
+    op.io = {in_(pts, form_limbs(form) * 8), out_(out, form_limbs(form) * 8)};
+    op.launch = [form](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0]) || !aligned8(d[1])) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        const int grid = ew_grid(c, cnt * 3);
+        if (form == CHEETAH_AFFINE)
+            hipLaunchKernelGGL((k_neg<0>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt);
+        else  // ProjectivePoint::neg and JacobianPoint::neg are the same map (x, -y, z)
+            hipLaunchKernelGGL((k_neg<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
+static int32_t eq_op(cheetah_ctx* ctx, bool host, const u64* a, const u64* b, int form, u8* flags, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, form, form)) return rc;
+    Op op;
+    op.n = n;
+    op.io = {in_(a, form_limbs(form) * 8), in_(b, form_limbs(form) * 8), out_(flags, 1)};
+    op.launch = [form](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0]) || !aligned8(d[1])) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        const int grid = ew_grid(c, cnt);
+#define LAUNCH(F) hipLaunchKernelGGL((k_point_eq<F>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), at<u8>(d, 2), cnt)
+        if (form == CHEETAH_AFFINE) LAUNCH(0);
+        else if (form == CHEETAH_PROJECTIVE) LAUNCH(1);
+        else LAUNCH(2);
+#undef LAUNCH
         HIP_TRY(c, hipGetLastError());
         return CHEETAH_OK;
     };
@@ -1434,10 +1474,28 @@ extern "C" int32_t cheetah_add_batch(cheetah_ctx* ctx, const uint64_t* lhs, int 
     return add_op(ctx, true, lhs, lhs_form, rhs, rhs_form, out, n);
 }
 extern "C" int32_t cheetah_double_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
-    return double_op(ctx, false, pts, form, out, n);
+    return double_op(ctx, false, pts, form, 1, out, n);
 }
 extern "C" int32_t cheetah_double_batch(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
-    return double_op(ctx, true, pts, form, out, n);
+    return double_op(ctx, true, pts, form, 1, out, n);
+}
+extern "C" int32_t cheetah_double_multi_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int form, uint32_t k, uint64_t* out, size_t n) {
+    return double_op(ctx, false, pts, form, k, out, n);
+}
+extern "C" int32_t cheetah_double_multi_batch(cheetah_ctx* ctx, const uint64_t* pts, int form, uint32_t k, uint64_t* out, size_t n) {
+    return double_op(ctx, true, pts, form, k, out, n);
+}
+extern "C" int32_t cheetah_neg_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
+    return neg_op(ctx, false, pts, form, out, n);
+}
+extern "C" int32_t cheetah_neg_batch(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
+    return neg_op(ctx, true, pts, form, out, n);
+}
+extern "C" int32_t cheetah_eq_batch_dev(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, int form, uint8_t* flags, size_t n) {
+    return eq_op(ctx, false, a, b, form, flags, n);
+}
+extern "C" int32_t cheetah_eq_batch(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, int form, uint8_t* flags, size_t n) {
+    return eq_op(ctx, true, a, b, form, flags, n);
 }
 
 // -------------------------------------------------------------- encodings -----

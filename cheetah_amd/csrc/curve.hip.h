@@ -374,6 +374,21 @@ CH_DEV Proj jac_add_mixed(const Proj& s, const Affine& r) {
     return o;
 }
 
+// ConstantTimeEq for JacobianPoint (src/curve/jacobian.rs:134-154) and ProjectivePoint (src/curve/projective.rs:118-135)
+CH_DEV bool jac_eq(const Proj& s, const Proj& o) {
+    const Fp6 z1_sq = fp6_square(s.z), z2_sq = fp6_square(o.z);
+    const Fp6 x1 = fp6_mul(s.x, z2_sq), x2 = fp6_mul(o.x, z1_sq);
+    const Fp6 y1 = fp6_mul(fp6_mul(s.y, z2_sq), o.z), y2 = fp6_mul(fp6_mul(o.y, z1_sq), s.z);
+    const bool sz = fp6_is_zero(s.z), oz = fp6_is_zero(o.z);
+    return (sz && oz) || (!sz && !oz && fp6_eq(x1, x2) && fp6_eq(y1, y2));
+}
+CH_DEV bool proj_eq(const Proj& s, const Proj& o) {
+    const Fp6 x1 = fp6_mul(s.x, o.z), x2 = fp6_mul(o.x, s.z);
+    const Fp6 y1 = fp6_mul(s.y, o.z), y2 = fp6_mul(o.y, s.z);
+    const bool sz = fp6_is_zero(s.z), oz = fp6_is_zero(o.z);
+    return (sz && oz) || (!sz && !oz && fp6_eq(x1, x2) && fp6_eq(y1, y2));
+}
+
 // Single-point normalisations (one Fp6 inversion each).
 // src/curve/affine.rs:64-78
 CH_DEV Affine affine_from_proj(const Proj& p) {

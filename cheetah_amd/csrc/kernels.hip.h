@@ -1528,11 +1528,49 @@ __global__ void __launch_bounds__(BLOCK) k_add(const u64* __restrict__ lhs, cons
         store_proj(out, nullptr, i, o);
     }
 }
+// ::double_multi(k): k >= 1 iterated ::double (src/curve/projective.rs:322-331, src/curve/jacobian.rs:341-350)
 template <int FORM>
-__global__ void __launch_bounds__(BLOCK) k_double(const u64* __restrict__ pts, u64* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(BLOCK) k_double(const u64* __restrict__ pts, u64* __restrict__ out, size_t n, u32 k) {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        const Proj s = load_proj(pts + 18 * i);
-        store_proj(out, nullptr, i, FORM == 1 ? proj_double(s) : jac_double(s));
+        Proj s = load_proj(pts + 18 * i);
+        for (u32 r = 0; r < k; r++) s = FORM == 1 ? proj_double(s) : jac_double(s);
+        store_proj(out, nullptr, i, s);
+    }
+}
+// -P: AffinePoint::neg (FORM 0, src/curve/affine.rs:164-175: the identity keeps y = 1), ProjectivePoint::neg
+// (src/curve/projective.rs:447-453), JacobianPoint::neg (src/curve/jacobian.rs:443-449).  One Fp6 per thread: x and z
+// pass through (canonicalised), y is negated.
+template <int FORM>
+__global__ void __launch_bounds__(BLOCK) k_neg(const u64* __restrict__ pts, u64* __restrict__ out, size_t n) {
+    constexpr int W = FORM == 0 ? 2 : 3;  // Fp6 values per point
+    for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < n * W; e += (size_t)gridDim.x * BLOCK) {
+        const size_t i = e / W;
+        const int c = (int)(e - i * W);
+        Fp6 v = load_fp6(pts + 6 * e);
+        if (c == 1) {
+            bool ident = false;
+            if (FORM == 0) ident = affine_is_identity_encoding(load_fp6(pts + 6 * (e - 1)), v);
+            v = fp6_select(fp6_neg(v), v, ident);
+        }
+        store_fp6_canonical(out + 6 * e, v);
+    }
+}
+// flags[i] = a[i].ct_eq(&b[i]) for AffinePoint (src/curve/affine.rs:132-144), ProjectivePoint
+// (src/curve/projective.rs:118-135), JacobianPoint (src/curve/jacobian.rs:134-154)
+template <int FORM>
+__global__ void __launch_bounds__(BLOCK) k_point_eq(const u64* __restrict__ a, const u64* __restrict__ b, u8* __restrict__ flags,
+                                                    size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        bool eq;
+        if (FORM == 0) {
+            const Affine p = load_affine(a + 12 * i), q = load_affine(b + 12 * i);
+            const bool pi = affine_is_identity_encoding(p.x, p.y), qi = affine_is_identity_encoding(q.x, q.y);
+            eq = (pi && qi) || (!pi && !qi && fp6_eq(p.x, q.x) && fp6_eq(p.y, q.y));
+        } else {
+            const Proj p = load_proj(a + 18 * i), q = load_proj(b + 18 * i);
+            eq = FORM == 1 ? proj_eq(p, q) : jac_eq(p, q);
+        }
+        flags[i] = eq ? 1 : 0;
     }
 }
 

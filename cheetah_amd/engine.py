@@ -304,6 +304,51 @@ class Engine:
         self._check(self._lib.cheetah_double_batch(self._h, a.ctypes.data, form, out.ctypes.data, len(a)))
         return out
 
+    def double_multi_batch(self, pts, k, form=JACOBIAN, out=None):
+        """out[i] = 2^k pts[i]: ::double_multi(k) (src/curve/projective.rs:322-331, src/curve/jacobian.rs:341-350)."""
+        if _is_torch(pts):
+            a = self._dev(pts, 8, 18)
+            out = self._empty((a.shape[0], 18), torch.uint64) if out is None else self._dev(out, 8, 18)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_double_multi_batch_dev(self._h, a.data_ptr(), form, int(k), out.data_ptr(), a.shape[0]))
+            return out
+        a = self._np(pts, np.uint64, 18)
+        out = np.empty((len(a), 18), np.uint64)
+        self._check(self._lib.cheetah_double_multi_batch(self._h, a.ctypes.data, form, int(k), out.ctypes.data, len(a)))
+        return out
+
+    def neg_batch(self, pts, form=AFFINE):
+        """out[i] = -pts[i] (src/curve/affine.rs:164-175, projective.rs:447-453, jacobian.rs:443-449)."""
+        w = self._out_width(form)
+        if _is_torch(pts):
+            a = self._dev(pts, 8, w)
+            out = self._empty((a.shape[0], w), torch.uint64)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_neg_batch_dev(self._h, a.data_ptr(), form, out.data_ptr(), a.shape[0]))
+            return out
+        a = self._np(pts, np.uint64, w)
+        out = np.empty((len(a), w), np.uint64)
+        self._check(self._lib.cheetah_neg_batch(self._h, a.ctypes.data, form, out.ctypes.data, len(a)))
+        return out
+
+    def eq_batch(self, a, b, form=AFFINE):
+        """flags[i] = a[i] == b[i] as points: ct_eq (src/curve/affine.rs:132-144, projective.rs:118-135, jacobian.rs:134-154)."""
+        w = self._out_width(form)
+        if _is_torch(a):
+            x, y = self._dev(a, 8, w), self._dev(b, 8, w)
+            if x.shape != y.shape:
+                raise ValueError("shape mismatch")
+            flags = self._empty((x.shape[0],), torch.uint8)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_eq_batch_dev(self._h, x.data_ptr(), y.data_ptr(), form, flags.data_ptr(), x.shape[0]))
+            return flags
+        x, y = self._np(a, np.uint64, w), self._np(b, np.uint64, w)
+        if x.shape != y.shape:
+            raise ValueError("shape mismatch")
+        flags = np.empty(len(x), np.uint8)
+        self._check(self._lib.cheetah_eq_batch(self._h, x.ctypes.data, y.ctypes.data, form, flags.ctypes.data, len(x)))
+        return flags
+
     # -- multi-scalar ladders, subgroup check, cofactor clearing ----------------------
     def _many(self, fname, pts, scalars, m, ns, in_form, out_form):
         w, wi = self._out_width(out_form), self._out_width(in_form)

@@ -293,6 +293,26 @@ inline std::vector<ProjectivePoint> double_batch(const Context& ctx, const std::
     return out;
 }
 
+// ProjectivePoint::double_multi(k), src/curve/projective.rs:322-331
+inline std::vector<ProjectivePoint> double_multi_batch(const Context& ctx, const std::vector<ProjectivePoint>& p, uint32_t k) {
+    std::vector<ProjectivePoint> out(p.size());
+    ctx.check(cheetah_double_multi_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, k, u64p(out.data()), p.size()));
+    return out;
+}
+// -&ProjectivePoint = ProjectivePoint::neg, src/curve/projective.rs:447-453
+inline std::vector<ProjectivePoint> neg_batch(const Context& ctx, const std::vector<ProjectivePoint>& p) {
+    std::vector<ProjectivePoint> out(p.size());
+    ctx.check(cheetah_neg_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, u64p(out.data()), p.size()));
+    return out;
+}
+// ProjectivePoint == ProjectivePoint (ConstantTimeEq), src/curve/projective.rs:118-135
+inline std::vector<uint8_t> eq_batch(const Context& ctx, const std::vector<ProjectivePoint>& a, const std::vector<ProjectivePoint>& b) {
+    if (a.size() != b.size()) throw Error(CHEETAH_ERR_INVALID, "length mismatch");
+    std::vector<uint8_t> flags(a.size());
+    ctx.check(cheetah_eq_batch(ctx.get(), u64p(a.data()), u64p(b.data()), CHEETAH_PROJECTIVE, flags.data(), a.size()));
+    return flags;
+}
+
 // ---- point encodings (src/curve/encoding.rs) ---------------------------------------
 struct CompressedPoint {
     std::array<uint8_t, 49> bytes;  // src/curve/encoding.rs:29

@@ -265,6 +265,23 @@ int32_t cheetah_add_batch_dev(cheetah_ctx *ctx, const uint64_t *lhs, int lhs_for
                               uint64_t *out, size_t n);
 int32_t cheetah_double_batch(cheetah_ctx *ctx, const uint64_t *pts, int form, uint64_t *out, size_t n);
 int32_t cheetah_double_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form, uint64_t *out, size_t n);
+/* out[i] = 2^k pts[i] by k iterated ::double, k >= 1 (the reference asserts it):
+ *                             ProjectivePoint::double_multi  src/curve/projective.rs:322-331
+ *                             JacobianPoint::double_multi    src/curve/jacobian.rs:341-350 */
+int32_t cheetah_double_multi_batch(cheetah_ctx *ctx, const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
+int32_t cheetah_double_multi_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
+/* out[i] = -pts[i], form AFFINE (n x 12), PROJECTIVE or JACOBIAN (n x 18), canonical limbs:
+ *                             AffinePoint::neg      src/curve/affine.rs:164-175  (the identity (0, 1) stays (0, 1))
+ *                             ProjectivePoint::neg  src/curve/projective.rs:447-453
+ *                             JacobianPoint::neg    src/curve/jacobian.rs:443-449 */
+int32_t cheetah_neg_batch(cheetah_ctx *ctx, const uint64_t *pts, int form, uint64_t *out, size_t n);
+int32_t cheetah_neg_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form, uint64_t *out, size_t n);
+/* flags[i] = 1 if a[i] and b[i] are the same point (whatever their representatives), else 0; both arrays in `form`:
+ *                             ConstantTimeEq for AffinePoint      src/curve/affine.rs:132-144
+ *                                                ProjectivePoint  src/curve/projective.rs:118-135
+ *                                                JacobianPoint    src/curve/jacobian.rs:134-154 */
+int32_t cheetah_eq_batch(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *b, int form, uint8_t *flags, size_t n);
+int32_t cheetah_eq_batch_dev(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *b, int form, uint8_t *flags, size_t n);
 
 /* ---- point encodings (src/curve/encoding.rs) ------------------------------------
  * cheetah_encode_uncompressed_batch  AffinePoint::to_uncompressed = UncompressedPoint::from_affine   :169-183

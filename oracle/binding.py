@@ -86,6 +86,9 @@ def lib():
         "ora_proj_eq": (C.c_int, [u64p, u64p]),
         "ora_add_batch": (None, [u64p, C.c_int, u64p, C.c_int, u64p, C.c_size_t]),
         "ora_double_batch": (None, [u64p, C.c_int, u64p, C.c_size_t]),
+        "ora_double_multi_batch": (None, [u64p, C.c_int, C.c_uint32, u64p, C.c_size_t]),
+        "ora_neg_batch": (None, [u64p, C.c_int, u64p, C.c_size_t]),
+        "ora_eq_batch": (None, [u64p, u64p, C.c_int, u8p, C.c_size_t]),
         "ora_jac_to_affine": (None, [u64p, u64p, u8p]),
         "ora_jac_is_on_curve": (C.c_int, [u64p]),
         "ora_mjac_double_unchecked": (None, [u64p, u64p]),
@@ -327,3 +330,26 @@ def double_batch(pts, form):
     out = np.empty_like(a)
     lib().ora_double_batch(a, form, out, len(a))
     return out
+
+
+def double_multi_batch(pts, form, k):
+    """::double_multi(k) (src/curve/projective.rs:322-331, src/curve/jacobian.rs:341-350)."""
+    a = _u64(pts).reshape(-1, 18)
+    out = np.empty_like(a)
+    lib().ora_double_multi_batch(a, form, k, out, len(a))
+    return out
+
+
+def neg_batch(pts, form):
+    a = _u64(pts).reshape(-1, 12 if form == 0 else 18)
+    out = np.empty_like(a)
+    lib().ora_neg_batch(a, form, out, len(a))
+    return out
+
+
+def eq_batch(a, b, form):
+    a = _u64(a).reshape(-1, 12 if form == 0 else 18)
+    b = _u64(b).reshape(a.shape)
+    flags = np.empty(len(a), np.uint8)
+    lib().ora_eq_batch(a, b, form, flags, len(a))
+    return flags

@@ -1444,6 +1444,50 @@ void ora_double_batch(const u64 *pts, int form, u64 *out, size_t n) {
         emit_point(form == 1 ? proj_double(s) : jac_double(s), 0, out, NULL, i, 1);
     }
 }
+/* ProjectivePoint / JacobianPoint::double_multi(k): k >= 1 iterated ::double (src/curve/projective.rs:322-331,
+ * src/curve/jacobian.rs:341-350) */
+void ora_double_multi_batch(const u64 *pts, int form, uint32_t k, u64 *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        proj s = proj_load(pts + 18 * i);
+        for (uint32_t r = 0; r < k; r++) s = form == 1 ? proj_double(s) : jac_double(s);
+        emit_point(s, 0, out, NULL, i, 1);
+    }
+}
+/* -P: AffinePoint::neg (src/curve/affine.rs:164-175: the identity keeps y = 1), ProjectivePoint::neg
+ * (src/curve/projective.rs:447-453), JacobianPoint::neg (src/curve/jacobian.rs:443-449); canonical limbs */
+void ora_neg_batch(const u64 *pts, int form, u64 *out, size_t n) {
+    const size_t w = form == 0 ? 12 : 18;
+    for (size_t i = 0; i < n; i++) {
+        fp6 x = fp6_load(pts + w * i), y = fp6_load(pts + w * i + 6);
+        if (form == 0) {
+            affine a = {x, y, (uint8_t)(fp6_is_zero(x) && fp6_eq(y, FP6_ONE))};
+            a = affine_neg(a);
+            x = a.x;
+            y = a.y;
+        } else {
+            y = fp6_neg(y);
+            fp6_store(out + w * i + 12, fp6_canonical(fp6_load(pts + w * i + 12)));
+        }
+        fp6_store(out + w * i, fp6_canonical(x));
+        fp6_store(out + w * i + 6, fp6_canonical(y));
+    }
+}
+/* flags[i] = a[i].ct_eq(&b[i]): ConstantTimeEq for AffinePoint (src/curve/affine.rs:132-144, (0, 1) = the identity at the ABI),
+ * ProjectivePoint (src/curve/projective.rs:118-135), JacobianPoint (src/curve/jacobian.rs:134-154) */
+void ora_eq_batch(const u64 *a, const u64 *b, int form, uint8_t *flags, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (form == 0) {
+            affine p = affine_load(a + 12 * i, 0), q = affine_load(b + 12 * i, 0);
+            p.inf = (uint8_t)(fp6_is_zero(p.x) && fp6_eq(p.y, FP6_ONE));
+            q.inf = (uint8_t)(fp6_is_zero(q.x) && fp6_eq(q.y, FP6_ONE));
+            flags[i] = (uint8_t)affine_eq(p, q);
+        } else {
+            proj p = proj_load(a + 18 * i), q = proj_load(b + 18 * i);
+            flags[i] = (uint8_t)(form == 1 ? proj_eq(p, q) : jac_eq(p, q));
+        }
+    }
+}
 /* AffinePoint::is_on_curve, src/curve/affine.rs:364-368; (0, 1) is the identity's encoding at the ABI */
 int ora_affine_is_on_curve(const u64 *xy) {
     affine a = affine_load(xy, 0);

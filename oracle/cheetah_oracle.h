@@ -132,6 +132,9 @@ int ora_jac_eq(const uint64_t *p, const uint64_t *q);
 int ora_proj_eq(const uint64_t *p, const uint64_t *q);
 void ora_add_batch(const uint64_t *lhs, int lhs_form, const uint64_t *rhs, int rhs_form, uint64_t *out, size_t n);
 void ora_double_batch(const uint64_t *pts, int form, uint64_t *out, size_t n);
+void ora_double_multi_batch(const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n); /* ::double_multi(k) */
+void ora_neg_batch(const uint64_t *pts, int form, uint64_t *out, size_t n);                      /* ::neg, three point types */
+void ora_eq_batch(const uint64_t *a, const uint64_t *b, int form, uint8_t *flags, size_t n);    /* ::ct_eq, three point types */
 int ora_num_threads(void);
 void ora_fp6_mul_batch(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 void ora_fp6_square_batch(const uint64_t *a, uint64_t *out, size_t n);

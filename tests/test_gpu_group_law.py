@@ -165,3 +165,41 @@ def test_add_batch_rejects_bad_forms(eng):
         eng.add_batch(a, a, PROJECTIVE, JACOBIAN)
     with pytest.raises(CheetahError):
         eng.double_batch(a, AFFINE)
+
+
+@pytest.mark.parametrize("form", [PROJECTIVE, JACOBIAN])
+def test_double_multi_neg_eq_match_the_oracle(eng, ora, form):
+    """::double_multi(k), ::neg and ::ct_eq (src/curve/projective.rs:322-331, :447-453, :118-135; src/curve/jacobian.rs:341-350,
+    :443-449, :134-154; AffinePoint: src/curve/affine.rs:164-175, :132-144) on the batch of special cases above."""
+    from cheetah_amd import CheetahError
+    n = 2048
+    lhs, rhs, rhs_aff = special_cases(eng, ora, form, n, 400 + form)
+    for k in (1, 2, 5):
+        want = ora.double_multi_batch(lhs, form, k)
+        assert np.array_equal(host(eng.double_multi_batch(dev(lhs), k, form)), want)
+    assert np.array_equal(eng.double_multi_batch(lhs, 3, form), ora.double_multi_batch(lhs, form, 3))
+    assert np.array_equal(ora.double_multi_batch(lhs, form, 1), ora.double_batch(lhs, form))
+    with pytest.raises(CheetahError):
+        eng.double_multi_batch(lhs, 0, form)
+    # neg: three point types, identities included ((0, 1) stays (0, 1))
+    assert np.array_equal(host(eng.neg_batch(dev(lhs), form)), ora.neg_batch(lhs, form))
+    assert np.array_equal(eng.neg_batch(rhs_aff, AFFINE), ora.neg_batch(rhs_aff, AFFINE))
+    neg_aff = host(eng.neg_batch(dev(rhs_aff), AFFINE))
+    assert np.array_equal(neg_aff, ora.neg_batch(rhs_aff, AFFINE)) and np.array_equal(neg_aff[7], IDENT_AFF)
+    # eq: slots 0 (same point, two representatives), 14 (same representative), 11 (O == O), 5 (P vs -P), 3 / 7 (O vs Q)
+    want = ora.eq_batch(lhs, rhs, form)
+    got = host_u8(eng.eq_batch(dev(lhs), dev(rhs), form))
+    assert np.array_equal(got, want)
+    assert got[0] == 1 and got[14] == 1 and got[11] == 1 and got[5] == 0 and got[3] == 0 and got[7] == 0 and got[1] == 0
+    assert np.array_equal(eng.eq_batch(lhs, rhs, form), want)
+    nl = eng.neg_batch(lhs, form)
+    assert np.array_equal(eng.eq_batch(eng.neg_batch(nl, form), lhs, form), np.ones(n, np.uint8))   # -(-P) == P
+    # affine
+    aff_l, _ = eng.batch_normalize(lhs, form)
+    want = ora.eq_batch(aff_l, rhs_aff, AFFINE)
+    assert np.array_equal(host_u8(eng.eq_batch(dev(aff_l), dev(rhs_aff), AFFINE)), want)
+    assert want[0] == 1 and want[11] == 1 and want[5] == 0
+
+
+def host_u8(t):
+    return t.cpu().numpy()
