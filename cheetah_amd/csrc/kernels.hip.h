@@ -665,11 +665,18 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const D
                                                                         const u64* __restrict__ wide,
                                                                         const u8* __restrict__ scalars, u64* __restrict__ out,
                                                                         u8* __restrict__ inf, size_t n) {
+#ifdef CH_WIDE_SCALAR  // experiment: the table read from global memory at wave-uniform addresses (scalar loads, selects on SGPR
+                       // operands), no LDS copy -- measured 136 M/s against 149 with the LDS copy (tools/gen_bench.py), not used
+    const u64* s_wide = wide;
+    const int t = threadIdx.x;
+    const Affine shift = load_affine(tab->shift);
+#else
     __shared__ u64 s_wide[WIDE_WINDOWS * WIDE_ENTRIES * 12];
     const int t = threadIdx.x;
     for (int w = t; w < WIDE_WINDOWS * WIDE_ENTRIES * 12; w += WIDE_BLOCK) s_wide[w] = wide[w];
     const Affine shift = load_affine(tab->shift);
     __syncthreads();
+#endif
     const size_t nround = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
     for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
         const size_t i = round * WIDE_BLOCK + t;
