@@ -23,7 +23,10 @@
  *    calls are issued on the context's stream.  `_dev` entry points take DEVICE pointers (memory of the
  *    context's first device; 8-byte aligned, Fp6 arrays 16-byte aligned) and are asynchronous on that stream;
  *    the others take HOST pointers and return after the results are back: per device a pipeline of chunks
- *    (upload / kernels / download overlapped, staging buffers kept in the context: no allocation per call).
+ *    (upload / kernels / download overlapped; staging kept in the context and grown to the largest call seen, so a
+ *    repeated call allocates nothing: two sets of device buffers and, for calls that move 8 MB or more per chunk, two
+ *    sets of page-locked host buffers of at most 160 MB each, filled and emptied by up to four host threads of the
+ *    library that live only for the duration of the call).
  *  - with several devices every call shards [0, n) into contiguous ranges, one per device, runs them
  *    concurrently and gathers the results into the caller's arrays (host arrays, or the first device's).
  *  - the caller owns all buffers; the library keeps no pointer after return.
