@@ -329,6 +329,9 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
 // 70 % of the memory pipeline's capacity while it computes -- the two overlap, but not perfectly (2.1 ms lies between
 // max = 1.5 and sum = 2.4).  The arithmetic alone, measured with -DCH_BN_NOMEM (no loads, stores elided), takes 1.80 ms at
 // this shape and 1.75 ms at (4, 3, 4): the kernel runs at 86 % of its own compute floor, whatever the occupancy.
+// A build that requested every record straight into LDS two steps ahead (global_load_lds_dwordx4, a ring of 18 KiB per
+// wave, vmcnt counted by hand; results bit-identical) measured 2.15 ms against 2.06 on the same box: deeper prefetch is
+// not what is missing either, and that kernel was not kept.
 #ifndef CH_BN_CHUNK
 #define CH_BN_CHUNK 8
 #endif
