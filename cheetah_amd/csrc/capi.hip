@@ -460,15 +460,19 @@ static int32_t host_pipeline(cheetah_ctx* c, const Op& op, size_t off, size_t cn
     while (chunk > 512 && chunk * unit_bytes > ((size_t)160 << 20)) chunk = (chunk / 2 + 255) / 256 * 256;  // bounds the staging
     const size_t nch = (cnt + chunk - 1) / chunk;
     const int sets = nch > 1 ? 2 : 1;
-    const bool pinned = chunk * unit_bytes >= ((size_t)8 << 20);
+    bool pinned = chunk * unit_bytes >= ((size_t)8 << 20);
     for (int s = 0; s < sets; s++) {
         if (c->stage[s].size() < nio) c->stage[s].resize(nio);
         if (c->pin[s].size() < nio) c->pin[s].resize(nio);
         for (size_t j = 0; j < nio; j++) {
             if (used(op.io[j]))
                 if (int32_t rc = ensure_slot(c, c->stage[s][j], chunk * op.io[j].stride, c->stream)) return rc;
-            if (pinned && moved(op.io[j]))
-                if (int32_t rc = ensure_pinned(c, c->pin[s][j], chunk * op.io[j].stride)) return rc;
+            if (pinned && moved(op.io[j]) && ensure_pinned(c, c->pin[s][j], chunk * op.io[j].stride)) {
+                // no page-locked memory to be had (a locked-memory limit, a busy host): the direct copies still work
+                (void)hipGetLastError();
+                c->err.clear();
+                pinned = false;
+            }
         }
     }
     std::vector<void*> d(nio);
