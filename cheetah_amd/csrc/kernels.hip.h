@@ -22,6 +22,9 @@ constexpr int BLOCK = 256;
 #ifndef CH_GEN_WAVES
 #define CH_GEN_WAVES 4
 #endif
+#ifndef CH_VT_PARK
+#define CH_VT_PARK 48  // NAF kernels: the wave adds once this many of its 64 lanes are parked at a non-zero digit
+#endif
 #ifndef CH_MANY_WAVES
 #define CH_MANY_WAVES 2
 #endif
@@ -1065,7 +1068,7 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
             const u64 m_can = __builtin_amdgcn_ballot_w64(can);
             const u64 m_pend = __builtin_amdgcn_ballot_w64(pd != 0);
             if (m_can == 0 && m_pend == 0) break;
-            if (m_pend != 0 && (__builtin_popcountll(m_pend) >= 48 || m_can == 0)) {
+            if (m_pend != 0 && (__builtin_popcountll(m_pend) >= CH_VT_PARK || m_can == 0)) {
                 if (pd != 0) {
                     const int e = (pd < 0 ? -pd : pd) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
                     Affine q;
@@ -1202,7 +1205,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
             const u64 m_pend = __builtin_amdgcn_ballot_w64(pd != 0);
             if (m_can == 0 && m_pend == 0) break;
             bool rescan = false;
-            if (m_pend != 0 && (__builtin_popcountll(m_pend) >= 48 || m_can == 0)) {
+            if (m_pend != 0 && (__builtin_popcountll(m_pend) >= CH_VT_PARK || m_can == 0)) {
                 if (pd != 0) {
                     const int e = (pd < 0 ? -pd : pd) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
                     Affine q;
