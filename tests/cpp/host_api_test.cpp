@@ -101,6 +101,23 @@ int main() {
             auto fx = from_x_batch(ctx, {one, zero, x2}, dinf, dsome);
             EXPECT(dsome[0] == 0 && dsome[1] == 1 && dinf[1] == 1 && dsome[2] == 1 && fx[2].x.c == x2.c);
         }
+        // group law over batches (src/curve/projective.rs tests test_projective_addition / test_doubling / negation):
+        // 2G + 2G == double(2G) == 4G, 2G + affine 2G too, 2G + (-2G) is the identity, double_multi(2)(G-multiple) == 4x
+        {
+            std::vector<ProjectivePoint> p2 = {gp[0]};
+            auto s1 = add_batch(ctx, p2, p2);
+            auto s2 = add_mixed_batch(ctx, p2, std::vector<AffinePoint>{g2[0]});
+            auto d1 = double_batch(ctx, p2);
+            auto n1 = neg_batch(ctx, p2);
+            auto z1 = add_batch(ctx, p2, n1);
+            auto d2 = double_multi_batch(ctx, p2, 2);                  // 8G
+            auto g8 = add_batch(ctx, d1, d1);
+            EXPECT(eq_batch(ctx, s1, d1)[0] == 1 && eq_batch(ctx, s2, d1)[0] == 1 && eq_batch(ctx, d2, g8)[0] == 1);
+            EXPECT(eq_batch(ctx, s1, p2)[0] == 0 && z1[0].z.c == zero.c);
+            std::vector<ProjectivePoint> chk4 = {s1[0], d1[0]};
+            batch_normalize(ctx, chk4, q, infinity);
+            EXPECT(q[0].x.c == g4[0].x.c && q[0].y.c == g4[0].y.c && q[1].x.c == g4[0].x.c && q[1].y.c == g4[0].y.c);
+        }
         // length mismatch is an error, not UB
         bool threw = false;
         try {
