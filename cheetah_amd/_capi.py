@@ -34,6 +34,10 @@ SIGNATURES = {
     "cheetah_double_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_double_multi_batch": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
     "cheetah_double_multi_batch_dev": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
+    "cheetah_double_multi_unchecked_batch": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
+    "cheetah_double_multi_unchecked_batch_dev": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
+    "cheetah_add_mixed_unchecked_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz]),
+    "cheetah_add_mixed_unchecked_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz]),
     "cheetah_neg_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_neg_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_eq_batch": (C.c_int32, [_vp, _vp, _vp, _i, _vp, _sz]),

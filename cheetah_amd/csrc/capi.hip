@@ -1430,6 +1430,33 @@ static int32_t double_op(cheetah_ctx* ctx, bool host, const u64* pts, int form, 
     };
     return run_op(ctx, host, op);
 }
+static int32_t unchecked_op(cheetah_ctx* ctx, bool host, const u64* lhs, int form, const u64* rhs_xy, u32 k, u64* out, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (form != CHEETAH_PROJECTIVE && form != CHEETAH_JACOBIAN)
+        return fail(ctx, CHEETAH_ERR_INVALID, "form must be CHEETAH_PROJECTIVE or CHEETAH_JACOBIAN");
+    const bool add = rhs_xy != nullptr;
+    if (!add && k < 1) return fail(ctx, CHEETAH_ERR_INVALID, "double_multi_unchecked needs at least one doubling (the reference asserts n >= 1)");
+    Op op;
+    op.n = n;
+    if (add) op.io = {in_(lhs, 18 * 8), in_(rhs_xy, 12 * 8), out_(out, 18 * 8)};
+    else op.io = {in_(lhs, 18 * 8), out_(out, 18 * 8)};
+    op.launch = [form, add, k](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0]) || !aligned8(d[1]) || (add && !aligned8(d[2]))) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        const int grid = ew_grid(c, cnt);
+        if (add && form == CHEETAH_PROJECTIVE)
+            hipLaunchKernelGGL((k_add_mixed_unchecked<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), at<u64>(d, 2), cnt);
+        else if (add)
+            hipLaunchKernelGGL((k_add_mixed_unchecked<2>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), at<u64>(d, 2), cnt);
+        else if (form == CHEETAH_PROJECTIVE)
+            hipLaunchKernelGGL((k_double_unchecked<1>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt, k);
+        else
+            hipLaunchKernelGGL((k_double_unchecked<2>), dim3(grid), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), at<u64>(d, 1), cnt, k);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, op);
+}
 static int32_t neg_op(cheetah_ctx* ctx, bool host, const u64* pts, int form, u64* out, size_t n) {
     if (!ctx) return CHEETAH_ERR_INVALID;
     if (int32_t rc = check_forms(ctx, form, form)) return rc;
@@ -1488,6 +1515,23 @@ extern "C" int32_t cheetah_double_multi_batch_dev(cheetah_ctx* ctx, const uint64
 }
 extern "C" int32_t cheetah_double_multi_batch(cheetah_ctx* ctx, const uint64_t* pts, int form, uint32_t k, uint64_t* out, size_t n) {
     return double_op(ctx, true, pts, form, k, out, n);
+}
+extern "C" int32_t cheetah_double_multi_unchecked_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int form, uint32_t k, uint64_t* out,
+                                                           size_t n) {
+    return unchecked_op(ctx, false, pts, form, nullptr, k, out, n);
+}
+extern "C" int32_t cheetah_double_multi_unchecked_batch(cheetah_ctx* ctx, const uint64_t* pts, int form, uint32_t k, uint64_t* out, size_t n) {
+    return unchecked_op(ctx, true, pts, form, nullptr, k, out, n);
+}
+extern "C" int32_t cheetah_add_mixed_unchecked_batch_dev(cheetah_ctx* ctx, const uint64_t* lhs, int form, const uint64_t* rhs_xy,
+                                                         uint64_t* out, size_t n) {
+    if (ctx && !rhs_xy && n) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    return unchecked_op(ctx, false, lhs, form, rhs_xy, 0, out, n);
+}
+extern "C" int32_t cheetah_add_mixed_unchecked_batch(cheetah_ctx* ctx, const uint64_t* lhs, int form, const uint64_t* rhs_xy, uint64_t* out,
+                                                     size_t n) {
+    if (ctx && !rhs_xy && n) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    return unchecked_op(ctx, true, lhs, form, rhs_xy, 0, out, n);
 }
 extern "C" int32_t cheetah_neg_batch_dev(cheetah_ctx* ctx, const uint64_t* pts, int form, uint64_t* out, size_t n) {
     return neg_op(ctx, false, pts, form, out, n);

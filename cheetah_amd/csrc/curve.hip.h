@@ -374,6 +374,35 @@ CH_DEV Proj jac_add_mixed(const Proj& s, const Affine& r) {
     return o;
 }
 
+// JacobianPoint::double_unchecked (src/curve/jacobian.rs:409-439) and ::add_mixed_unchecked (:559-595): the formulas
+// above without their identity / equality selections (add_mixed_unchecked keeps "rhs is the identity -> self").
+CH_DEV Proj jac_double_unchecked(const Proj& s) {
+    MJac m;
+    m.x = s.x;
+    m.y = s.y;
+    m.z = s.z;
+    m.z4 = fp6_square(fp6_square(s.z));
+    m = mjac_double_impl<false>(m);
+    Proj o;
+    o.x = m.x;
+    o.y = m.y;
+    o.z = m.z;
+    return o;
+}
+CH_DEV Proj jac_add_mixed_unchecked(const Proj& s, const Affine& r) {
+    MJac m;
+    m.x = s.x;
+    m.y = s.y;
+    m.z = s.z;
+    m.z4 = s.z;  // not read: the fresh-z4 form without its z4 output
+    m = mjac_add_mixed_impl<true, false>(m, r);
+    Proj o;
+    o.x = m.x;
+    o.y = m.y;
+    o.z = m.z;
+    return o;
+}
+
 // ConstantTimeEq for JacobianPoint (src/curve/jacobian.rs:134-154) and ProjectivePoint (src/curve/projective.rs:118-135)
 CH_DEV bool jac_eq(const Proj& s, const Proj& o) {
     const Fp6 z1_sq = fp6_square(s.z), z2_sq = fp6_square(o.z);

@@ -1550,6 +1550,26 @@ __global__ void __launch_bounds__(BLOCK) k_double(const u64* __restrict__ pts, u
         store_proj(out, nullptr, i, s);
     }
 }
+// The incomplete forms as operations of their own: ::double_multi_unchecked(k) (src/curve/projective.rs:337-346,
+// src/curve/jacobian.rs:356-365) and ::add_mixed_unchecked (src/curve/projective.rs:576-610, src/curve/jacobian.rs:559-595).
+template <int FORM>
+__global__ void __launch_bounds__(BLOCK) k_double_unchecked(const u64* __restrict__ pts, u64* __restrict__ out, size_t n, u32 k) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Proj s = load_proj(pts + 18 * i);
+        for (u32 r = 0; r < k; r++) s = FORM == 1 ? proj_double_unchecked(s) : jac_double_unchecked(s);
+        store_proj(out, nullptr, i, s);
+    }
+}
+template <int FORM>
+__global__ void __launch_bounds__(BLOCK) k_add_mixed_unchecked(const u64* __restrict__ lhs, const u64* __restrict__ rhs,
+                                                               u64* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const Proj s = load_proj(lhs + 18 * i);
+        Affine r = load_affine(rhs + 12 * i);
+        r.inf = affine_is_identity_encoding(r.x, r.y);
+        store_proj(out, nullptr, i, FORM == 1 ? proj_add_mixed_unchecked(s, r) : jac_add_mixed_unchecked(s, r));
+    }
+}
 // -P: AffinePoint::neg (FORM 0, src/curve/affine.rs:164-175: the identity keeps y = 1), ProjectivePoint::neg
 // (src/curve/projective.rs:447-453), JacobianPoint::neg (src/curve/jacobian.rs:443-449).  One Fp6 per thread: x and z
 // pass through (canonicalised), y is negated.

@@ -317,6 +317,36 @@ class Engine:
         self._check(self._lib.cheetah_double_multi_batch(self._h, a.ctypes.data, form, int(k), out.ctypes.data, len(a)))
         return out
 
+    def double_multi_unchecked_batch(self, pts, k, form=JACOBIAN):
+        """::double_multi_unchecked(k) (src/curve/projective.rs:337-346, src/curve/jacobian.rs:356-365); k = 1: ::double_unchecked."""
+        if _is_torch(pts):
+            a = self._dev(pts, 8, 18)
+            out = self._empty((a.shape[0], 18), torch.uint64)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_double_multi_unchecked_batch_dev(self._h, a.data_ptr(), form, int(k), out.data_ptr(), a.shape[0]))
+            return out
+        a = self._np(pts, np.uint64, 18)
+        out = np.empty((len(a), 18), np.uint64)
+        self._check(self._lib.cheetah_double_multi_unchecked_batch(self._h, a.ctypes.data, form, int(k), out.ctypes.data, len(a)))
+        return out
+
+    def add_mixed_unchecked_batch(self, lhs, rhs_xy, form=JACOBIAN):
+        """::add_mixed_unchecked (src/curve/projective.rs:576-610, src/curve/jacobian.rs:559-595)."""
+        if _is_torch(lhs):
+            a, b = self._dev(lhs, 8, 18), self._dev(rhs_xy, 8, 12)
+            if a.shape[0] != b.shape[0]:
+                raise ValueError("lhs and rhs must hold the same number of points")
+            out = self._empty((a.shape[0], 18), torch.uint64)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_add_mixed_unchecked_batch_dev(self._h, a.data_ptr(), form, b.data_ptr(), out.data_ptr(), a.shape[0]))
+            return out
+        a, b = self._np(lhs, np.uint64, 18), self._np(rhs_xy, np.uint64, 12)
+        if len(a) != len(b):
+            raise ValueError("lhs and rhs must hold the same number of points")
+        out = np.empty((len(a), 18), np.uint64)
+        self._check(self._lib.cheetah_add_mixed_unchecked_batch(self._h, a.ctypes.data, form, b.ctypes.data, out.ctypes.data, len(a)))
+        return out
+
     def neg_batch(self, pts, form=AFFINE):
         """out[i] = -pts[i] (src/curve/affine.rs:164-175, projective.rs:447-453, jacobian.rs:443-449)."""
         w = self._out_width(form)

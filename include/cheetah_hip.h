@@ -273,6 +273,18 @@ int32_t cheetah_double_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form
  *                             JacobianPoint::double_multi    src/curve/jacobian.rs:341-350 */
 int32_t cheetah_double_multi_batch(cheetah_ctx *ctx, const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
 int32_t cheetah_double_multi_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
+/* The incomplete ("unchecked") formulas as operations of their own, for callers that chain them as the reference's
+ * ladders do; form CHEETAH_PROJECTIVE or CHEETAH_JACOBIAN, L2 results.  As in the reference they are only meaningful
+ * away from their exceptional cases (the identity for the doublings; equal, opposite or identity operands on the
+ * left for the addition -- an identity rhs (0, 1) returns lhs):
+ *   out[i] = 2^k pts[i], k >= 1   ::double_multi_unchecked / ::double_unchecked (k = 1)
+ *                                 src/curve/projective.rs:337-346, :400-443; src/curve/jacobian.rs:356-365, :409-439
+ *   out[i] = lhs[i] + rhs[i]      ::add_mixed_unchecked, rhs affine (n x 12)
+ *                                 src/curve/projective.rs:576-610; src/curve/jacobian.rs:559-595 */
+int32_t cheetah_double_multi_unchecked_batch(cheetah_ctx *ctx, const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
+int32_t cheetah_double_multi_unchecked_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
+int32_t cheetah_add_mixed_unchecked_batch(cheetah_ctx *ctx, const uint64_t *lhs, int form, const uint64_t *rhs_xy, uint64_t *out, size_t n);
+int32_t cheetah_add_mixed_unchecked_batch_dev(cheetah_ctx *ctx, const uint64_t *lhs, int form, const uint64_t *rhs_xy, uint64_t *out, size_t n);
 /* out[i] = -pts[i], form AFFINE (n x 12), PROJECTIVE or JACOBIAN (n x 18), canonical limbs:
  *                             AffinePoint::neg      src/curve/affine.rs:164-175  (the identity (0, 1) stays (0, 1))
  *                             ProjectivePoint::neg  src/curve/projective.rs:447-453

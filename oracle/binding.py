@@ -88,6 +88,8 @@ def lib():
         "ora_double_batch": (None, [u64p, C.c_int, u64p, C.c_size_t]),
         "ora_double_multi_batch": (None, [u64p, C.c_int, C.c_uint32, u64p, C.c_size_t]),
         "ora_neg_batch": (None, [u64p, C.c_int, u64p, C.c_size_t]),
+        "ora_double_multi_unchecked_batch": (None, [u64p, C.c_int, C.c_uint32, u64p, C.c_size_t]),
+        "ora_add_mixed_unchecked_batch": (None, [u64p, C.c_int, u64p, u64p, C.c_size_t]),
         "ora_eq_batch": (None, [u64p, u64p, C.c_int, u8p, C.c_size_t]),
         "ora_jac_to_affine": (None, [u64p, u64p, u8p]),
         "ora_jac_is_on_curve": (C.c_int, [u64p]),
@@ -353,3 +355,18 @@ def eq_batch(a, b, form):
     flags = np.empty(len(a), np.uint8)
     lib().ora_eq_batch(a, b, form, flags, len(a))
     return flags
+
+
+def double_multi_unchecked_batch(pts, form, k):
+    a = _u64(pts).reshape(-1, 18)
+    out = np.empty_like(a)
+    lib().ora_double_multi_unchecked_batch(a, form, k, out, len(a))
+    return out
+
+
+def add_mixed_unchecked_batch(lhs, form, rhs_xy):
+    a = _u64(lhs).reshape(-1, 18)
+    b = _u64(rhs_xy).reshape(len(a), 12)
+    out = np.empty_like(a)
+    lib().ora_add_mixed_unchecked_batch(a, form, b, out, len(a))
+    return out

@@ -1454,6 +1454,26 @@ void ora_double_multi_batch(const u64 *pts, int form, uint32_t k, u64 *out, size
         emit_point(s, 0, out, NULL, i, 1);
     }
 }
+/* The incomplete ("unchecked") forms: ::double_multi_unchecked(k) = k iterated ::double_unchecked (src/curve/projective.rs:337-346,
+ * :400-443; src/curve/jacobian.rs:356-365, :409-439) and ::add_mixed_unchecked (src/curve/projective.rs:576-610,
+ * src/curve/jacobian.rs:559-595) */
+void ora_double_multi_unchecked_batch(const u64 *pts, int form, uint32_t k, u64 *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        proj s = proj_load(pts + 18 * i);
+        for (uint32_t r = 0; r < k; r++) s = form == 1 ? proj_double_unchecked(s) : jac_double_unchecked(s);
+        emit_point(s, 0, out, NULL, i, 1);
+    }
+}
+void ora_add_mixed_unchecked_batch(const u64 *lhs, int form, const u64 *rhs_xy, u64 *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        proj s = proj_load(lhs + 18 * i);
+        affine r = affine_load(rhs_xy + 12 * i, 0);
+        r.inf = (uint8_t)(fp6_is_zero(r.x) && fp6_eq(r.y, FP6_ONE));
+        emit_point(form == 1 ? proj_add_mixed_unchecked(s, r) : jac_add_mixed_unchecked(s, r), 0, out, NULL, i, 1);
+    }
+}
 /* -P: AffinePoint::neg (src/curve/affine.rs:164-175: the identity keeps y = 1), ProjectivePoint::neg
  * (src/curve/projective.rs:447-453), JacobianPoint::neg (src/curve/jacobian.rs:443-449); canonical limbs */
 void ora_neg_batch(const u64 *pts, int form, u64 *out, size_t n) {

@@ -133,6 +133,8 @@ int ora_proj_eq(const uint64_t *p, const uint64_t *q);
 void ora_add_batch(const uint64_t *lhs, int lhs_form, const uint64_t *rhs, int rhs_form, uint64_t *out, size_t n);
 void ora_double_batch(const uint64_t *pts, int form, uint64_t *out, size_t n);
 void ora_double_multi_batch(const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n); /* ::double_multi(k) */
+void ora_double_multi_unchecked_batch(const uint64_t *pts, int form, uint32_t k, uint64_t *out, size_t n);
+void ora_add_mixed_unchecked_batch(const uint64_t *lhs, int form, const uint64_t *rhs_xy, uint64_t *out, size_t n);
 void ora_neg_batch(const uint64_t *pts, int form, uint64_t *out, size_t n);                      /* ::neg, three point types */
 void ora_eq_batch(const uint64_t *a, const uint64_t *b, int form, uint8_t *flags, size_t n);    /* ::ct_eq, three point types */
 int ora_num_threads(void);

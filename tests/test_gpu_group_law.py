@@ -203,3 +203,24 @@ def test_double_multi_neg_eq_match_the_oracle(eng, ora, form):
 
 def host_u8(t):
     return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("form", [PROJECTIVE, JACOBIAN])
+def test_unchecked_formulas_match_the_oracle(eng, ora, form):
+    """::double_unchecked / ::double_multi_unchecked / ::add_mixed_unchecked (src/curve/projective.rs:337-346, :400-443, :576-610;
+    src/curve/jacobian.rs:356-365, :409-439, :559-595): the reference's own (X : Y : Z), exceptional operands included -- what
+    the incomplete formulas return there is arbitrary but determined, and the same here."""
+    n = 2048
+    lhs, rhs, rhs_aff = special_cases(eng, ora, form, n, 800 + form)
+    for k in (1, 4):
+        want = ora.double_multi_unchecked_batch(lhs, form, k)
+        assert np.array_equal(host(eng.double_multi_unchecked_batch(dev(lhs), k, form)), want)
+    assert np.array_equal(eng.double_multi_unchecked_batch(lhs, 2, form), ora.double_multi_unchecked_batch(lhs, form, 2))
+    want = ora.add_mixed_unchecked_batch(lhs, form, rhs_aff)
+    assert np.array_equal(host(eng.add_mixed_unchecked_batch(dev(lhs), dev(rhs_aff), form)), want)
+    assert np.array_equal(eng.add_mixed_unchecked_batch(lhs, rhs_aff, form), want)
+    assert np.array_equal(want[7], lhs[7] % np.uint64(P))          # an identity on the right returns the left operand
+    # away from the exceptional slots the unchecked and the complete forms are the same point
+    full = ora.add_batch(lhs, form, rhs_aff, AFFINE)
+    same = ora.eq_batch(want, full, form)
+    assert same[1] == 1 and same[2] == 1 and same[4] == 1
