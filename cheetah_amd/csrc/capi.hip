@@ -757,6 +757,35 @@ static int32_t fp6_unary_op(cheetah_ctx* ctx, bool host, const u64* a, u64* out,
     return run_op(ctx, host, op);
 }
 
+static int32_t fp6_op_op(cheetah_ctx* ctx, bool host, int op, const u64* a, const u64* b, u64 scalar, u64* out, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (op < 0 || op >= F6_OPS) return fail(ctx, CHEETAH_ERR_INVALID, "unknown cheetah_fp6_op");
+    const bool binary = op == F6_ADD || op == F6_SUB;
+    if (binary && !b && n) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    Op o;
+    o.n = n;
+    if (binary) o.io = {in_(a, 48), in_(b, 48), out_(out, 48)};
+    else o.io = {in_(a, 48), out_(out, 48)};
+    o.launch = [op, binary, scalar](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        const u64* bb = binary ? at<u64>(d, 1) : nullptr;
+        u64* oo = at<u64>(d, binary ? 2 : 1);
+        if (!aligned16(d[0]) || !aligned16(oo) || (bb && !aligned16(bb))) return fail(c, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
+        const size_t tiles = (cnt + BLOCK - 1) / BLOCK;
+        hipLaunchKernelGGL(k_fp6_op, dim3((unsigned)(tiles < ((size_t)1 << 22) ? tiles : ((size_t)1 << 22))), dim3(BLOCK), 0, c->stream, op,
+                           at<u64>(d, 0), bb, scalar, oo, cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, o);
+}
+extern "C" int32_t cheetah_fp6_op_batch_dev(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t scalar, uint64_t* out,
+                                            size_t n) {
+    return fp6_op_op(ctx, false, op, a, b, scalar, out, n);
+}
+extern "C" int32_t cheetah_fp6_op_batch(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t scalar, uint64_t* out, size_t n) {
+    return fp6_op_op(ctx, true, op, a, b, scalar, out, n);
+}
 extern "C" int32_t cheetah_fp6_mul_batch_dev(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     return fp6_mul_op(ctx, false, a, b, out, n);
 }

@@ -305,6 +305,35 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict
     }
 }
 
+// The coefficient-wise and structured Fp6 operations over a batch (one public entry point, cheetah_fp6_op_batch):
+// add / sub / neg / double / triple (src/fp6.rs:968-1029), mul_by_u32 / mul_by_fp (:428-464), make_canonical (:373-382),
+// the Frobenius maps (:1088-1123) and mul_by_3b (src/curve/mod.rs:54-106).  HBM-bound: the op is a run-time switch.
+enum Fp6Op { F6_ADD = 0, F6_SUB, F6_NEG, F6_DOUBLE, F6_TRIPLE, F6_MUL_BY_U32, F6_MUL_BY_FP, F6_CANONICAL, F6_FROBENIUS,
+             F6_FROBENIUS_DOUBLE, F6_FROBENIUS_TRIPLE, F6_MUL_BY_3B, F6_OPS };
+__global__ void __launch_bounds__(BLOCK) k_fp6_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64 scalar,
+                                                  u64* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const Fp6 x = load_fp6_vec(a + 6 * i);
+        Fp6 r;
+        switch (op) {
+            case F6_ADD: r = fp6_add(x, load_fp6_vec(b + 6 * i)); break;
+            case F6_SUB: r = fp6_sub(x, load_fp6_vec(b + 6 * i)); break;
+            case F6_NEG: r = fp6_neg(x); break;
+            case F6_DOUBLE: r = fp6_double(x); break;
+            case F6_TRIPLE: r = fp6_triple(x); break;
+            case F6_MUL_BY_U32: r = fp6_mul_by_fp(x, scalar & 0xffffffffull); break;  // the same element of Fp as Fp::mul_by_u32 gives
+            case F6_MUL_BY_FP: r = fp6_mul_by_fp(x, scalar); break;
+            case F6_FROBENIUS: r = fp6_frobenius(x); break;
+            case F6_FROBENIUS_DOUBLE: r = fp6_frobenius_double(x); break;
+            case F6_FROBENIUS_TRIPLE: r = fp6_frobenius_triple(x); break;
+            case F6_MUL_BY_3B: r = fp6_mul_by_3b(x); break;
+            default: r = x; break;  // F6_CANONICAL: the store canonicalises
+        }
+        store_fp6_vec_canonical(out + 6 * i, r);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // batch_normalize (config 4).  The reference runs ONE sequential Montgomery
 // chain over the whole slice (src/curve/projective.rs:897-930,

@@ -126,6 +126,39 @@ class Engine:
         self._check(self._lib.cheetah_fp6_square_batch(self._h, a.ctypes.data, out.ctypes.data, len(a)))
         return out
 
+    FP6_OPS = ("add", "sub", "neg", "double", "triple", "mul_by_u32", "mul_by_fp", "canonical", "frobenius", "frobenius_double",
+               "frobenius_triple", "mul_by_3b")
+
+    def fp6_op_batch(self, op, a, b=None, scalar=0):
+        """out[i] = op(a[i] [, b[i] | scalar]) for the coefficient-wise and structured Fp6 operations (src/fp6.rs:373-382,
+        :428-464, :968-1029, :1088-1123; mul_by_3b: src/curve/mod.rs:54-106); op is one of Engine.FP6_OPS."""
+        code = self.FP6_OPS.index(op)
+        binary = op in ("add", "sub")
+        if binary and b is None:
+            raise ValueError("%s needs two operands" % op)
+        if _is_torch(a):
+            a = self._dev(a, 8, 6)
+            bp = 0
+            if binary:
+                b = self._dev(b, 8, 6)
+                if a.shape != b.shape:
+                    raise ValueError("shape mismatch")
+                bp = b.data_ptr()
+            out = self._empty(a.shape, torch.uint64)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_fp6_op_batch_dev(self._h, code, a.data_ptr(), bp, int(scalar), out.data_ptr(), a.shape[0]))
+            return out
+        a = self._np(a, np.uint64, 6)
+        bp = 0
+        if binary:
+            b = self._np(b, np.uint64, 6)
+            if a.shape != b.shape:
+                raise ValueError("shape mismatch")
+            bp = b.ctypes.data
+        out = np.empty_like(a)
+        self._check(self._lib.cheetah_fp6_op_batch(self._h, code, a.ctypes.data, bp, int(scalar), out.ctypes.data, len(a)))
+        return out
+
     def _fp6_option(self, name, a):
         if _is_torch(a):
             a = self._dev(a, 8, 6)

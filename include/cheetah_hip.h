@@ -80,6 +80,20 @@ int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx *ctx, int cus);
 const char *cheetah_last_error(const cheetah_ctx *ctx); /* ctx may be NULL: last create error */
 const char *cheetah_version(void);
 
+/* ---- the other Fp6 operations over a batch ------------------------------------------
+ * out[i] = op(a[i] [, b[i] | scalar]), canonical limbs; b is read by ADD / SUB only, scalar by MUL_BY_U32 (its low 32 bits)
+ * and MUL_BY_FP (any u64, taken mod p):
+ *   ADD SUB NEG DOUBLE TRIPLE            src/fp6.rs:968-1029          MUL_BY_U32 MUL_BY_FP   src/fp6.rs:428-464
+ *   CANONICAL (make_canonical)           src/fp6.rs:373-382           MUL_BY_3B              src/curve/mod.rs:54-106
+ *   FROBENIUS, FROBENIUS_DOUBLE, FROBENIUS_TRIPLE (x -> x^p, x^(p^2), x^(p^3))              src/fp6.rs:1088-1123 */
+typedef enum {
+    CHEETAH_FP6_ADD = 0, CHEETAH_FP6_SUB, CHEETAH_FP6_NEG, CHEETAH_FP6_DOUBLE, CHEETAH_FP6_TRIPLE, CHEETAH_FP6_MUL_BY_U32,
+    CHEETAH_FP6_MUL_BY_FP, CHEETAH_FP6_CANONICAL, CHEETAH_FP6_FROBENIUS, CHEETAH_FP6_FROBENIUS_DOUBLE,
+    CHEETAH_FP6_FROBENIUS_TRIPLE, CHEETAH_FP6_MUL_BY_3B
+} cheetah_fp6_op;
+int32_t cheetah_fp6_op_batch(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t scalar, uint64_t *out, size_t n);
+int32_t cheetah_fp6_op_batch_dev(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t scalar, uint64_t *out, size_t n);
+
 /* ---- elementwise Fp6 -----------------------------------------------------
  * out[i] = a[i] * b[i]           Fp6::mul      src/fp6.rs:651-834
  * out[i] = a[i]^2                Fp6::square   src/fp6.rs:838-920

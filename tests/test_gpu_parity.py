@@ -601,6 +601,54 @@ def test_g_a_b_equals_g_ab_on_gpu(eng):
 
 
 
+def test_fp6_op_batch_vs_oracle(eng, ora):
+    """cheetah_fp6_op_batch: the coefficient-wise operations, the Frobenius maps and mul_by_3b (src/fp6.rs:373-382, :428-464,
+    :968-1029, :1088-1123, src/curve/mod.rs:54-106) on seeded elements plus edge limbs (0, 1, p - 1, p, 2^64 - 1), canonical
+    output; device and host arrays."""
+    n = 300
+    a, b = synth.fp6_elements(61, n).reshape(n, 6).copy(), synth.fp6_elements(62, n).reshape(n, 6).copy()
+    edge = np.array([0, 1, P - 1, P, 2**64 - 1, 2**32, 2**32 - 1], np.uint64)
+    a[:7, :] = edge[:, None]
+    b[:7, :] = edge[::-1][:, None]
+    a[7] = [2**64 - 1, P, 0, 1, P - 1, 2**63]
+    L = ora.lib()
+    def want(f, *extra):
+        out = np.zeros((n, 6), np.uint64)
+        for i in range(n):
+            o = np.zeros(6, np.uint64)
+            f(i, o)
+            out[i] = o % np.uint64(P)
+        return out
+    cases = [
+        ("add", True, 0, lambda i, o: L.ora_fp6_add(a[i].copy(), b[i].copy(), o)),
+        ("sub", True, 0, lambda i, o: L.ora_fp6_sub(a[i].copy(), b[i].copy(), o)),
+        ("neg", False, 0, lambda i, o: L.ora_fp6_neg(a[i].copy(), o)),
+        ("double", False, 0, lambda i, o: L.ora_fp6_double(a[i].copy(), o)),
+        ("triple", False, 0, lambda i, o: L.ora_fp6_triple(a[i].copy(), o)),
+        ("mul_by_u32", False, 0xFFFFFFFF, lambda i, o: L.ora_fp6_mul_by_u32(a[i].copy(), 0xFFFFFFFF, o)),
+        ("mul_by_u32", False, 7, lambda i, o: L.ora_fp6_mul_by_u32(a[i].copy(), 7, o)),
+        ("mul_by_fp", False, 2**64 - 1, lambda i, o: L.ora_fp6_mul_by_fp(a[i].copy(), 2**64 - 1, o)),
+        ("mul_by_fp", False, 0x123456789ABCDEF1, lambda i, o: L.ora_fp6_mul_by_fp(a[i].copy(), 0x123456789ABCDEF1, o)),
+        ("canonical", False, 0, lambda i, o: L.ora_fp6_canonical(a[i].copy(), o)),
+        ("frobenius", False, 0, lambda i, o: L.ora_fp6_frobenius(a[i].copy(), o)),
+        ("frobenius_double", False, 0, lambda i, o: L.ora_fp6_frobenius_double(a[i].copy(), o)),
+        ("frobenius_triple", False, 0, lambda i, o: L.ora_fp6_frobenius_triple(a[i].copy(), o)),
+        ("mul_by_3b", False, 0, lambda i, o: L.ora_mul_by_3b(a[i].copy(), o)),
+    ]
+    A, B = dev(a), dev(b)
+    for op, binary, scalar, f in cases:
+        w = want(f)
+        got = eng.fp6_op_batch(op, A, B if binary else None, scalar)
+        assert (host(got) == w).all(), (op, scalar)
+        got = eng.fp6_op_batch(op, a, b if binary else None, scalar)
+        assert (got == w).all(), (op, scalar, "host")
+    # x^(p^6) = x: three Frobenius maps twice over
+    x = A
+    for _ in range(2):
+        x = eng.fp6_op_batch("frobenius_triple", x)
+    assert (host(x) == a % np.uint64(P)).all()
+
+
 # ------------------------------------------ multi-scalar ladders and checks ----
 
 @pytest.mark.parametrize("m", [1, 2, 3])
