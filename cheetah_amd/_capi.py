@@ -38,6 +38,8 @@ SIGNATURES = {
     "cheetah_double_multi_unchecked_batch_dev": (C.c_int32, [_vp, _vp, _i, C.c_uint32, _vp, _sz]),
     "cheetah_add_mixed_unchecked_batch": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz]),
     "cheetah_add_mixed_unchecked_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _vp, _sz]),
+    "cheetah_fp_op_batch": (C.c_int32, [_vp, _i, _vp, _vp, C.c_uint64, _vp, _vp, _sz]),
+    "cheetah_fp_op_batch_dev": (C.c_int32, [_vp, _i, _vp, _vp, C.c_uint64, _vp, _vp, _sz]),
     "cheetah_fp6_op_batch": (C.c_int32, [_vp, _i, _vp, _vp, C.c_uint64, _vp, _sz]),
     "cheetah_fp6_op_batch_dev": (C.c_int32, [_vp, _i, _vp, _vp, C.c_uint64, _vp, _sz]),
     "cheetah_neg_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),

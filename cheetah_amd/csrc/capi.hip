@@ -328,6 +328,11 @@ static int lane_grid(const cheetah_ctx* ctx, size_t n_lanes_needed, int blocks_p
     return g ? (int)g : 1;
 }
 
+static int ew_grid(const cheetah_ctx* c, size_t n) {
+    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)c->num_cus * 8;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
 constexpr int ROUNDS_PER_LAUNCH = 2;
 
 // The arena is sized at creation for the single-scalar ladders; only the multi-scalar kernels with many points per
@@ -757,6 +762,32 @@ static int32_t fp6_unary_op(cheetah_ctx* ctx, bool host, const u64* a, u64* out,
     return run_op(ctx, host, op);
 }
 
+static int32_t fp_op_op(cheetah_ctx* ctx, bool host, int op, const u64* a, const u64* b, u64 scalar, u64* out, u8* is_some, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (op < 0 || op >= FP_OPS) return fail(ctx, CHEETAH_ERR_INVALID, "unknown cheetah_fp_op");
+    const bool binary = op == FP_ADD || op == FP_SUB || op == FP_MUL;
+    if (binary && !b && n) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    Op o;
+    o.n = n;
+    o.io = {in_(a, 8), in_(binary ? b : a, 8), out_(out, 8), out_(is_some, 1, /*optional*/ true)};
+    o.launch = [op, scalar](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned8(d[0]) || !aligned8(d[1]) || !aligned8(d[2])) return fail(c, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
+        hipLaunchKernelGGL(k_fp_op, dim3(ew_grid(c, cnt)), dim3(BLOCK), 0, c->stream, op, at<u64>(d, 0), at<u64>(d, 1), scalar, at<u64>(d, 2),
+                           at<u8>(d, 3), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, o);
+}
+extern "C" int32_t cheetah_fp_op_batch_dev(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t scalar, uint64_t* out,
+                                           uint8_t* is_some, size_t n) {
+    return fp_op_op(ctx, false, op, a, b, scalar, out, is_some, n);
+}
+extern "C" int32_t cheetah_fp_op_batch(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t scalar, uint64_t* out,
+                                       uint8_t* is_some, size_t n) {
+    return fp_op_op(ctx, true, op, a, b, scalar, out, is_some, n);
+}
 static int32_t fp6_op_op(cheetah_ctx* ctx, bool host, int op, const u64* a, const u64* b, u64 scalar, u64* out, size_t n) {
     if (!ctx) return CHEETAH_ERR_INVALID;
     if (op < 0 || op >= F6_OPS) return fail(ctx, CHEETAH_ERR_INVALID, "unknown cheetah_fp6_op");
@@ -1151,11 +1182,6 @@ extern "C" int32_t cheetah_multiply_batch_dev_noalloc(cheetah_ctx* ctx, const ui
 }
 
 // --------------------------------------------- multi-scalar ladders, checks -----
-
-static int ew_grid(const cheetah_ctx* c, size_t n) {
-    size_t tiles = (n + BLOCK - 1) / BLOCK, cap = (size_t)c->num_cus * 8;
-    return (int)(tiles < cap ? tiles : cap);
-}
 
 // multiply_double_with_basepoint_vartime with AFFINE results: out[i] = a_i P_i + b_i G as the sum of the two
 // single-scalar fast paths (fixed-window ladder with indexed lookups for a P, widened comb for b G) instead of the

@@ -334,6 +334,32 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_op(int op, const u64* __restrict_
     }
 }
 
+// The base-field operations over a batch (cheetah_fp_op_batch): Fp::add / sub / neg / double / triple / mul / square /
+// mul_by_u32 / invert / make_canonical (src/fp.rs:125-196, :335-359).  One element per lane, HBM-bound except invert.
+enum FpOp { FP_ADD = 0, FP_SUB, FP_NEG, FP_DOUBLE, FP_TRIPLE, FP_MUL, FP_SQUARE, FP_MUL_BY_U32, FP_INVERT, FP_CANONICAL, FP_OPS };
+__global__ void __launch_bounds__(BLOCK) k_fp_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64 scalar,
+                                                 u64* __restrict__ out, u8* __restrict__ is_some, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const u64 x = a[i];
+        u64 r;
+        switch (op) {
+            case FP_ADD: r = fp_add(x, b[i]); break;
+            case FP_SUB: r = fp_sub(x, b[i]); break;
+            case FP_NEG: r = fp_neg(x); break;
+            case FP_DOUBLE: r = fp_double(x); break;
+            case FP_TRIPLE: r = fp_triple(x); break;
+            case FP_MUL: r = fp_mul(x, b[i]); break;
+            case FP_SQUARE: r = fp_square(x); break;
+            case FP_MUL_BY_U32: r = fp_mul(x, scalar & 0xffffffffull); break;
+            case FP_INVERT: r = fp_invert(x); break;  // 0 -> 0, flagged none (CtOption, src/fp.rs:335-359)
+            default: r = x; break;
+        }
+        out[i] = fp_canonical(r);
+        if (op == FP_INVERT && is_some) is_some[i] = fp_is_zero(x) ? 0 : 1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // batch_normalize (config 4).  The reference runs ONE sequential Montgomery
 // chain over the whole slice (src/curve/projective.rs:897-930,

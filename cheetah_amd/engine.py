@@ -126,6 +126,40 @@ class Engine:
         self._check(self._lib.cheetah_fp6_square_batch(self._h, a.ctypes.data, out.ctypes.data, len(a)))
         return out
 
+    FP_OPS = ("add", "sub", "neg", "double", "triple", "mul", "square", "mul_by_u32", "invert", "canonical")
+
+    def fp_op_batch(self, op, a, b=None, scalar=0):
+        """out[i] = op(a[i] [, b[i] | scalar]) in the base field, one u64 per element (src/fp.rs:125-196, :335-359); op is one
+        of Engine.FP_OPS.  "invert" returns (out, is_some)."""
+        code = self.FP_OPS.index(op)
+        binary = op in ("add", "sub", "mul")
+        if binary and b is None:
+            raise ValueError("%s needs two operands" % op)
+        if _is_torch(a):
+            if a.dim() != 1 or a.element_size() != 8 or not a.is_contiguous() or not a.is_cuda:
+                raise ValueError("expected a contiguous 1-D CUDA tensor of 8-byte elements")
+            bp = b.data_ptr() if binary else 0
+            if binary and b.shape != a.shape:
+                raise ValueError("shape mismatch")
+            out = self._empty(a.shape, torch.uint64)
+            some = self._empty(a.shape, torch.uint8) if op == "invert" else None
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_fp_op_batch_dev(self._h, code, a.data_ptr(), bp, int(scalar), out.data_ptr(),
+                                                          some.data_ptr() if some is not None else 0, a.shape[0]))
+            return (out, some) if op == "invert" else out
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        bp = 0
+        if binary:
+            b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1)
+            if a.shape != b.shape:
+                raise ValueError("shape mismatch")
+            bp = b.ctypes.data
+        out = np.empty_like(a)
+        some = np.empty(len(a), np.uint8) if op == "invert" else None
+        self._check(self._lib.cheetah_fp_op_batch(self._h, code, a.ctypes.data, bp, int(scalar), out.ctypes.data,
+                                                  some.ctypes.data if some is not None else 0, len(a)))
+        return (out, some) if op == "invert" else out
+
     FP6_OPS = ("add", "sub", "neg", "double", "triple", "mul_by_u32", "mul_by_fp", "canonical", "frobenius", "frobenius_double",
                "frobenius_triple", "mul_by_3b")
 

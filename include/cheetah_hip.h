@@ -80,6 +80,21 @@ int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx *ctx, int cus);
 const char *cheetah_last_error(const cheetah_ctx *ctx); /* ctx may be NULL: last create error */
 const char *cheetah_version(void);
 
+/* ---- the base field over a batch ----------------------------------------------------
+ * out[i] = op(a[i] [, b[i] | scalar]) in Fp = GF(2^64 - 2^32 + 1), one u64 per element, any u64 accepted (src/fp.rs:57),
+ * canonical output; b is read by ADD / SUB / MUL, scalar (low 32 bits) by MUL_BY_U32; INVERT maps 0 to 0 and, if is_some is
+ * not NULL, sets is_some[i] = 0 there (CtOption::none) and 1 elsewhere:
+ *   ADD SUB NEG DOUBLE TRIPLE   src/fp.rs:136-174      MUL SQUARE MUL_BY_U32   src/fp.rs:178-196 (reduce_u128 / reduce_u96, :623-667)
+ *   INVERT                      src/fp.rs:335-359      CANONICAL (make_canonical)   src/fp.rs:125-127 */
+typedef enum {
+    CHEETAH_FP_ADD = 0, CHEETAH_FP_SUB, CHEETAH_FP_NEG, CHEETAH_FP_DOUBLE, CHEETAH_FP_TRIPLE, CHEETAH_FP_MUL, CHEETAH_FP_SQUARE,
+    CHEETAH_FP_MUL_BY_U32, CHEETAH_FP_INVERT, CHEETAH_FP_CANONICAL
+} cheetah_fp_op;
+int32_t cheetah_fp_op_batch(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t scalar, uint64_t *out,
+                            uint8_t *is_some, size_t n);
+int32_t cheetah_fp_op_batch_dev(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t scalar, uint64_t *out,
+                                uint8_t *is_some, size_t n);
+
 /* ---- the other Fp6 operations over a batch ------------------------------------------
  * out[i] = op(a[i] [, b[i] | scalar]), canonical limbs; b is read by ADD / SUB only, scalar by MUL_BY_U32 (its low 32 bits)
  * and MUL_BY_FP (any u64, taken mod p):

@@ -601,6 +601,38 @@ def test_g_a_b_equals_g_ab_on_gpu(eng):
 
 
 
+def test_fp_op_batch_vs_python_ints(eng, ora):
+    """cheetah_fp_op_batch: the base field's operations (src/fp.rs:125-196, :335-359) against Python integers mod p and the
+    oracle, edge values and every pair of them included; any u64 is a legal input, outputs are canonical."""
+    rng = np.random.default_rng(9)
+    edge = [0, 1, 2, P - 2, P - 1, P, P + 1, 2**32 - 1, 2**32, 2**32 + 1, 2**63, 2**64 - 2**32, 2**64 - 1]
+    pairs = [(x, y) for x in edge for y in edge]
+    a = np.array([x for x, _ in pairs] + list(rng.integers(0, 2**64, 3000, dtype=np.uint64)), np.uint64)
+    b = np.array([y for _, y in pairs] + list(rng.integers(0, 2**64, 3000, dtype=np.uint64)), np.uint64)
+    ai, bi = [int(v) for v in a], [int(v) for v in b]
+    want = {
+        "add": [(x + y) % P for x, y in zip(ai, bi)], "sub": [(x - y) % P for x, y in zip(ai, bi)], "neg": [(-x) % P for x in ai],
+        "double": [2 * x % P for x in ai], "triple": [3 * x % P for x in ai], "mul": [x * y % P for x, y in zip(ai, bi)],
+        "square": [x * x % P for x in ai], "canonical": [x % P for x in ai],
+    }
+    A, B = dev(a), dev(b)
+    for op, w in want.items():
+        binary = op in ("add", "sub", "mul")
+        w = np.array(w, np.uint64)
+        assert (host(eng.fp_op_batch(op, A, B if binary else None)) == w).all(), op
+        assert (eng.fp_op_batch(op, a, b if binary else None) == w).all(), (op, "host")
+    for k in (0, 1, 7, 2**31, 2**32 - 1):
+        w = np.array([x * k % P for x in ai], np.uint64)
+        assert (host(eng.fp_op_batch("mul_by_u32", A, scalar=k)) == w).all(), k
+        assert int(ora.lib().ora_fp_mul_by_u32(ai[20], k)) % P == int(w[20])
+    inv, some = eng.fp_op_batch("invert", A)
+    inv, some = host(inv), host(some)
+    w = np.array([pow(x, P - 2, P) for x in ai], np.uint64)
+    assert (inv == w).all() and (some == np.array([x % P != 0 for x in ai], np.uint8)).all()
+    inv2, some2 = eng.fp_op_batch("invert", a)
+    assert (inv2 == w).all() and (some2 == some).all()
+
+
 def test_fp6_op_batch_vs_oracle(eng, ora):
     """cheetah_fp6_op_batch: the coefficient-wise operations, the Frobenius maps and mul_by_3b (src/fp6.rs:373-382, :428-464,
     :968-1029, :1088-1123, src/curve/mod.rs:54-106) on seeded elements plus edge limbs (0, 1, p - 1, p, 2^64 - 1), canonical
