@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Randomised differential run, GPU against the oracle: random entry point, forms, batch size, with special points
+(identities in every encoding, G, -G, repeated points) and special scalars (0, 1, q - 1, q, 2^255 - 1, bit 255 set) mixed
+into seeded batches.  usage: tools/fuzz_gpu.py <seconds> [seed].  Prints one line per mismatch and a summary; exit 1 on
+any mismatch.  Not a test (no fixed duration): tests/ holds the deterministic cases this found or could find."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE, Engine, synth
+from oracle import binding as ora
+
+P = 0xFFFFFFFF00000001
+Q = synth.Q
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ora.build()
+eng = Engine(0)
+G = ora.table("ora_generator_affine", 1)[0]
+IDENT = np.array([0] * 6 + [1] + [0] * 5, np.uint64)
+
+
+def dev(a):
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int64)).cuda().view(torch.uint64) if a.dtype == np.uint64 else torch.from_numpy(a).cuda()
+
+
+def host(t):
+    return t.view(torch.int64).cpu().numpy().view(np.uint64) if t.dtype == torch.uint64 else t.cpu().numpy()
+
+
+def le(k):
+    return np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+
+
+def scalars(n):
+    sc = synth.scalars(int(rng.integers(1, 1 << 30)), n).copy()
+    special = [0, 1, 2, 15, 16, Q - 1, Q, (1 << 255) - 1, (1 << 255) + 5, (1 << 256) - 1, 1 << 255]
+    for _ in range(int(rng.integers(0, 6))):
+        k = special[int(rng.integers(0, len(special)))]
+        if k >= 1 << 255 and rng.random() < 0.5:
+            continue
+        sc[int(rng.integers(0, n))] = le(k)
+    return sc
+
+
+def affine_points(n):
+    aff, _ = ora.mul_by_generator_batch(synth.scalars(int(rng.integers(1, 1 << 30)), n), 0)
+    aff = aff.copy()
+    for _ in range(int(rng.integers(0, 6))):
+        i = int(rng.integers(0, n))
+        c = int(rng.integers(0, 4))
+        if c == 0:
+            aff[i] = IDENT
+        elif c == 1:
+            aff[i] = G
+        elif c == 2:
+            aff[i] = np.concatenate([G[:6], (np.uint64(P) - G[6:]) % np.uint64(P)])
+        else:
+            aff[i] = aff[int(rng.integers(0, n))]
+    return aff
+
+
+def to_form(aff, form):
+    if form == AFFINE:
+        return aff
+    n = len(aff)
+    z = synth.fp6_elements(int(rng.integers(1, 1 << 30)), n).reshape(n, 6)
+    x, y = np.ascontiguousarray(aff[:, :6]), np.ascontiguousarray(aff[:, 6:])
+    if form == PROJECTIVE:
+        out = np.concatenate([ora.fp6_mul_batch(x, z).reshape(n, 6), ora.fp6_mul_batch(y, z).reshape(n, 6), z], axis=1)
+    else:
+        z2 = ora.fp6_square_batch(z).reshape(n, 6)
+        out = np.concatenate([ora.fp6_mul_batch(x, z2).reshape(n, 6), ora.fp6_mul_batch(y, ora.fp6_mul_batch(z2, z).reshape(n, 6)).reshape(n, 6), z], axis=1)
+    out = np.ascontiguousarray(out)
+    ident = (aff[:, :6] == 0).all(axis=1) & (aff[:, 6] == 1) & (aff[:, 7:] == 0).all(axis=1)
+    for i in np.nonzero(ident)[0]:
+        c = int(rng.integers(0, 3))
+        if c == 0:
+            out[i, 12:] = 0                                   # (X, Y, 0), arbitrary X, Y
+        elif c == 1:
+            out[i] = [0] * 6 + [1] + [0] * 5 + [0] * 6 if form == PROJECTIVE else [1] + [0] * 5 + [1] + [0] * 5 + [0] * 6
+        else:
+            out[i, 12:] = P                                   # z = 0 written as p
+    return out
+
+
+def pick_forms():
+    in_form = int(rng.integers(0, 3))
+    outs = [AFFINE] + ([PROJECTIVE] if in_form != JACOBIAN else []) + ([JACOBIAN] if in_form != PROJECTIVE else [])
+    return in_form, outs[int(rng.integers(0, len(outs)))]
+
+
+bad = runs = 0
+t_end = time.time() + budget
+t_note = time.time() + 30
+while time.time() < t_end:
+    if time.time() > t_note:
+        print("... %d runs, %d findings" % (runs, bad), flush=True)
+        t_note = time.time() + 30
+    n = int(rng.integers(1, 1500))
+    case = int(rng.integers(0, 8))
+    in_form, out_form = pick_forms()
+    aff = affine_points(n)
+    pts = to_form(aff, in_form)
+    use_host = rng.random() < 0.25
+    D = (lambda a: a) if use_host else dev
+    H = (lambda a: a) if use_host else host
+    name = "?"
+    try:
+        if case in (0, 1):
+            vt = case == 1
+            k = scalars(n)
+            name = "multiply%s %d->%d" % ("_vartime" if vt else "", in_form, out_form)
+            want = ora.multiply_batch(pts, in_form, k, out_form, vartime=vt)
+            got = (eng.multiply_vartime_batch if vt else eng.multiply_batch)(D(pts), D(k), in_form, out_form)
+        elif case in (2, 3):
+            vt = case == 3
+            m = int(rng.integers(1, 4))
+            if n < m:
+                continue
+            g = n // m
+            k = scalars(g * m)
+            p = pts[: g * m]
+            name = "multiply_many%s m=%d %d->%d" % ("_vartime" if vt else "", m, in_form, out_form)
+            want = ora.multiply_many_batch(p, in_form, k, m, out_form, vartime=vt)
+            got = (eng.multiply_many_vartime_batch if vt else eng.multiply_many_batch)(D(p), D(k), m, in_form, out_form)
+        elif case == 4:
+            k = scalars(2 * n)
+            name = "a P + b G %d->%d" % (in_form, out_form)
+            want = ora.multiply_many_batch(pts, in_form, k, 1, out_form, vartime=True, with_basepoint=True)
+            got = eng.multiply_double_with_basepoint_vartime_batch(D(pts), D(k), in_form, out_form)
+        elif case == 5:
+            form = PROJECTIVE if in_form == AFFINE else in_form
+            p = to_form(aff, form)
+            name = "batch_normalize %d" % form
+            want = ora.batch_normalize(p, form == JACOBIAN)
+            got = eng.batch_normalize(D(p), form)
+        elif case == 6:
+            form = PROJECTIVE if in_form == AFFINE else in_form
+            p, q = to_form(aff, form), to_form(affine_points(n), form)
+            if rng.random() < 0.5:
+                name = "add %d" % form
+                want = (ora.add_batch(p, form, q, form),)
+                got = (eng.add_batch(D(p), D(q), form),)
+            else:
+                qa = affine_points(n)
+                name = "add_mixed %d" % form
+                want = (ora.add_batch(p, form, qa, AFFINE),)
+                got = (eng.add_batch(D(p), D(qa), form, AFFINE),)
+        else:
+            k = scalars(n)
+            of = [AFFINE, PROJECTIVE, JACOBIAN][int(rng.integers(0, 3))]
+            if of != JACOBIAN:
+                k[:, 31] &= 0x7F                              # BasePointTable's range (top nibble <= 7)
+            name = "mul_by_generator ->%d" % of
+            want = ora.mul_by_generator_batch(k, of)
+            got = eng.mul_by_generator_batch(D(k), of)
+        runs += 1
+        for w, g_ in zip(want, got):
+            g_ = H(g_)
+            if not np.array_equal(np.asarray(g_).reshape(np.asarray(w).shape), w):
+                idx = np.nonzero((np.asarray(g_).reshape(np.asarray(w).shape) != w).reshape(len(w), -1).any(axis=1))[0]
+                print("MISMATCH %s n=%d host=%s first at %s (seed %d, run %d)" % (name, n, use_host, idx[:5], seed, runs), flush=True)
+                bad += 1
+                break
+    except Exception as e:  # an error code where the oracle has an answer is a finding too
+        print("ERROR %s n=%d host=%s: %s" % (name, n, use_host, e), flush=True)
+        bad += 1
+print("fuzz: %d runs, %d findings, seed %d, %.0f s" % (runs, bad, seed, budget), flush=True)
+eng.close()
+sys.exit(1 if bad else 0)
