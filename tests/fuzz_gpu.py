@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run, GPU against the oracle: random entry point, forms, batch size, with special points
 (identities in every encoding, G, -G, repeated points) and special scalars (0, 1, q - 1, q, 2^255 - 1, bit 255 set) mixed
-into seeded batches.  usage: tools/fuzz_gpu.py <seconds> [seed].  Prints one line per mismatch and a summary; exit 1 on
+into seeded batches.  usage: tests/fuzz_gpu.py <seconds> [seed].  Prints one line per mismatch and a summary; exit 1 on
 any mismatch.  Not a test (no fixed duration): tests/ holds the deterministic cases this found or could find."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
