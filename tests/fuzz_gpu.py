@@ -100,7 +100,7 @@ while time.time() < t_end:
         print("... %d runs, %d findings" % (runs, bad), flush=True)
         t_note = time.time() + 30
     n = int(rng.integers(1, 1500))
-    case = int(rng.integers(0, 8))
+    case = int(rng.integers(0, 12))
     in_form, out_form = pick_forms()
     aff = affine_points(n)
     pts = to_form(aff, in_form)
@@ -149,6 +149,44 @@ while time.time() < t_end:
                 name = "add_mixed %d" % form
                 want = (ora.add_batch(p, form, qa, AFFINE),)
                 got = (eng.add_batch(D(p), D(qa), form, AFFINE),)
+        elif case == 8:
+            form = int(rng.integers(0, 3))
+            p = to_form(aff, form)
+            other = affine_points(n)
+            mix = np.where((rng.random(n) < 0.5)[:, None], aff, other)
+            q = to_form(np.ascontiguousarray(mix), form)
+            name = "eq %d" % form
+            want = (ora.eq_batch(p, q, form),)
+            got = (eng.eq_batch(D(p), D(q), form),)
+        elif case == 9:
+            form = PROJECTIVE if in_form == AFFINE else in_form
+            p = to_form(aff, form)
+            kk = int(rng.integers(1, 5))
+            name = "double_multi(%d) %d" % (kk, form)
+            want = (ora.double_multi_batch(p, form, kk), ora.neg_batch(p, form))
+            got = (eng.double_multi_batch(D(p), kk, form), eng.neg_batch(D(p), form))
+        elif case == 10:
+            hb = np.tile(le(0x2150B48E071EF610049BC3F5D54304E4A), (n, 1))
+            qb = np.tile(le(Q), (n, 1))
+            name = "clear_cofactor / is_torsion_free %d" % in_form
+            w1 = ora.multiply_batch(pts, in_form, hb, AFFINE, vartime=True)
+            w2 = ora.multiply_batch(pts, in_form, qb, PROJECTIVE if in_form == PROJECTIVE else JACOBIAN, vartime=True)[1]
+            g1 = eng.clear_cofactor_batch(D(pts), in_form, AFFINE)
+            want = (w1[0], w1[1], w2)
+            got = (g1[0], g1[1], eng.is_torsion_free_batch(D(pts), in_form))
+        elif case == 11:
+            inf = ((aff[:, :6] == 0).all(axis=1) & (aff[:, 6] == 1) & (aff[:, 7:] == 0).all(axis=1)).astype(np.uint8)
+            comp = bool(rng.integers(0, 2))
+            name = "encode / decode %s" % ("compressed" if comp else "uncompressed")
+            enc = ora.encode_batch(aff, inf, comp)
+            e = (eng.to_compressed_batch if comp else eng.to_uncompressed_batch)(D(aff), D(inf))
+            bad_rec = enc.copy()
+            bad_rec[:: 7, int(rng.integers(0, enc.shape[1]))] ^= 1 << int(rng.integers(0, 8))   # most of these are rejected
+            chk = bool(rng.integers(0, 2))
+            w = (ora.decode_compressed_batch if comp else ora.decode_uncompressed_batch)(bad_rec, chk)
+            d = (eng.from_compressed_batch if comp else eng.from_uncompressed_batch)(D(bad_rec), chk)
+            want = (enc,) + tuple(w)
+            got = (e,) + tuple(d)
         else:
             k = scalars(n)
             of = [AFFINE, PROJECTIVE, JACOBIAN][int(rng.integers(0, 3))]
