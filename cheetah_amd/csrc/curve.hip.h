@@ -239,6 +239,50 @@ CH_DEV MJac mjac_add_mixed_unchecked_fresh_z4(const MJac& s, const Affine& r) {
     return mjac_add_mixed_impl<true, WANT_Z4>(s, r);
 }
 
+// ---- XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2): no counterpart in the reference ----
+// Used where only the affine result is returned and the schedule is additions only (k_mul_by_generator_wide): a mixed
+// addition is 8 M + 2 S here against the 8 M + 3 S of ModifiedJacobianPoint::add_mixed_unchecked, and there is no
+// doubling to pay for the fourth coordinate.  Incomplete like that one (s != +-r, s not the identity); r.inf returns s.
+struct XYZZ {
+    Fp6 x, y, zz, zzz;
+};
+CH_DEV XYZZ xyzz_from_affine(const Affine& a) {  // a is not the identity
+    XYZZ o;
+    o.x = a.x;
+    o.y = a.y;
+    o.zz = fp6_one();
+    o.zzz = fp6_one();
+    return o;
+}
+CH_DEV XYZZ xyzz_add_mixed_unchecked(const XYZZ& s, const Affine& r) {
+    XYZZ o;
+    Fp6 p = fp6_sub(fp6_mul(r.x, s.zz), s.x);
+    Fp6 rr = fp6_sub(fp6_mul(r.y, s.zzz), s.y);
+    Fp6 pp = fp6_square(p);
+    Fp6 ppp = fp6_mul(p, pp);
+    o.zz = fp6_select(fp6_mul(s.zz, pp), s.zz, r.inf);
+    o.zzz = fp6_select(fp6_mul(s.zzz, ppp), s.zzz, r.inf);
+    Fp6 q = fp6_mul(s.x, pp);
+    Fp6 x3 = fp6_square(rr);
+    x3 = fp6_sub(x3, ppp);
+    x3 = fp6_sub(x3, fp6_double(q));
+    Fp6 y3 = fp6_mul(rr, fp6_sub(q, x3));
+    o.x = fp6_select(x3, s.x, r.inf);
+    y3 = fp6_sub(y3, fp6_mul(s.y, ppp));
+    o.y = fp6_select(y3, s.y, r.inf);
+    return o;
+}
+CH_DEV Affine affine_from_xyzz(const XYZZ& s) {  // ZZ = 0: the identity
+    bool some;
+    Fp6 inv = fp6_invert(fp6_mul(s.zz, s.zzz), &some);
+    Affine a;
+    a.x = fp6_mul(s.x, fp6_mul(inv, s.zzz));
+    a.y = fp6_mul(s.y, fp6_mul(inv, s.zz));
+    a.inf = false;
+    if (!some) a = affine_identity();
+    return a;
+}
+
 // ---- complete group law (batch entry points cheetah_add_batch / cheetah_double_batch) ----
 
 // ProjectivePoint::add_mixed, src/curve/projective.rs:518-569 (Renes-Costello-Batina Algorithm 2 with Z2 = 1;

@@ -2,6 +2,7 @@
 // Fp6 element) per lane; 256-thread workgroups = 4 waves = one wave per SIMD.
 #pragma once
 #include "curve.hip.h"
+#include <utility>
 
 namespace cheetah {
 
@@ -609,29 +610,61 @@ CH_DEV void load_scalar(const u8* scalars, size_t i, u64 k[4]) {
 
 // ---------------------------------------------------------------------------
 // Fixed base, constant time (config 2): BasePointTable::multiply,
-// src/lookup.rs:189-206.  The 24 KiB table sits in LDS; a lookup reads all 8
+// src/lookup.rs:189-206.  The 24 KiB table sits in LDS; a lookup goes over all 8
 // entries of the digit's sub-table (every lane the same addresses: an LDS
-// broadcast) and keeps the one it wants by selects -- the reference's
+// broadcast) and each lane keeps the one it wants -- the reference's
 // constant-time scan (src/lookup.rs:81-102).
+// Left to the compiler, the scan-and-select form of such a lookup (read entry j, keep it where |d| == j) becomes one
+// `s_cbranch_execz` per read -- a branch on the digits the wave holds -- around single LDS reads that are each waited
+// for.  It is written out instead: entry j is read once per wave at its wave-uniform address with only the lanes that
+// want it enabled (EXEC = {|d| == j}), straight into the result registers.  No select instructions, no branch and no
+// address that depends on a digit, and the N x 6 reads of a lookup are all in flight before the one wait.
 // GENERIC: the table may hold identities (a caller-supplied base of small order), stored as (0, 1).
-template <bool GENERIC = false>
-CH_DEV Affine lds_lookup8(const u64* sub /* 8 x 12 limbs in LDS */, int d) {
+template <int J>
+CH_DEV void lds_read_entry_where(u64x2 (&q)[6], u32 addr, u32 key) {
+    u64 saved;
+    asm volatile(
+        "v_cmp_eq_u32_e32 vcc, %[j], %[key]\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "ds_read_b128 %[q0], %[a] offset:%[o0]\n\t"
+        "ds_read_b128 %[q1], %[a] offset:%[o1]\n\t"
+        "ds_read_b128 %[q2], %[a] offset:%[o2]\n\t"
+        "ds_read_b128 %[q3], %[a] offset:%[o3]\n\t"
+        "ds_read_b128 %[q4], %[a] offset:%[o4]\n\t"
+        "ds_read_b128 %[q5], %[a] offset:%[o5]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [q4] "+v"(q[4]), [q5] "+v"(q[5]), [sv] "=&s"(saved)
+        : [key] "v"(key), [a] "v"(addr), [j] "n"(J), [o0] "n"((J - 1) * 96), [o1] "n"((J - 1) * 96 + 16),
+          [o2] "n"((J - 1) * 96 + 32), [o3] "n"((J - 1) * 96 + 48), [o4] "n"((J - 1) * 96 + 64), [o5] "n"((J - 1) * 96 + 80)
+        : "vcc", "memory");
+}
+template <bool GENERIC, int... Js>
+CH_DEV Affine lds_lookup_seq(const u64* sub, int d, std::integer_sequence<int, Js...>) {
     const int neg = d < 0;
-    const int dabs = neg ? -d : d;
-    Affine t = affine_identity();
+    const u32 dabs = (u32)(neg ? -d : d);  // -128 -> 128: entry 128, negated (src/lookup.rs:86-98)
+    const u32 addr = (u32)(uintptr_t)(const __attribute__((address_space(3))) u64*)sub;
+    u64x2 q[6];
 #pragma unroll
-    for (int j = 1; j <= 8; j++) {
-        const bool hit = (dabs == j);
+    for (int l = 0; l < 6; l++) q[l] = u64x2{0, 0};
+    q[3].x = 1;  // (0, 1): what a lane with digit 0 keeps
+    (lds_read_entry_where<Js + 1>(q, addr, dabs), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]));
+    Affine t;
 #pragma unroll
-        for (int l = 0; l < 6; l++) {
-            u64 vx = sub[(j - 1) * 12 + l], vy = sub[(j - 1) * 12 + 6 + l];
-            t.x.c[l] = hit ? vx : t.x.c[l];
-            t.y.c[l] = hit ? vy : t.y.c[l];
-        }
-        t.inf = hit ? false : t.inf;
+    for (int l = 0; l < 3; l++) {
+        t.x.c[2 * l] = q[l].x;
+        t.x.c[2 * l + 1] = q[l].y;
+        t.y.c[2 * l] = q[3 + l].x;
+        t.y.c[2 * l + 1] = q[3 + l].y;
     }
+    t.inf = dabs == 0;
     if (GENERIC) t.inf = t.inf || affine_is_identity_encoding(t.x, t.y);
     return affine_cond_neg(t, neg);
+}
+// entry |d| (1-based) of N affine entries of 96 bytes at `sub` (LDS, 16-byte aligned), negated for d < 0; (0, 1, inf) for d = 0
+template <int N, bool GENERIC = false>
+CH_DEV Affine lds_lookup(const u64* sub, int d) {
+    return lds_lookup_seq<GENERIC>(sub, d, std::make_integer_sequence<int, N>{});
 }
 
 // A scalar outside what BasePointTable's LookupTable<8> covers (top nibble > 7): the element is
@@ -645,7 +678,7 @@ template <int OUT_FORM, bool GENERIC = false>
 __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ comb, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n) {
-    __shared__ u64 s_tab[32 * 8 * 12];
+    __shared__ __align__(16) u64 s_tab[32 * 8 * 12];
     __shared__ i8 s_digits[64 * BLOCK];
     const int t = threadIdx.x;
     for (int w = t; w < 32 * 8 * 12; w += BLOCK) s_tab[w] = comb[w];
@@ -662,9 +695,9 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const 
         __syncthreads();
         const bool in_range = (k[3] >> 60) <= 7;  // LookupTable<8> covers the top digit only then (Q3)
         Proj acc = proj_from_affine(shift);
-        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8<GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup<8, GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
         for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
-        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup8<GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup<8, GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
         acc = proj_add_mixed_unchecked(acc, mshift4);
         if (active) {
             if (in_range)
@@ -682,10 +715,12 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const 
 // radix-64 digits d_j in [-32, 32) (k = sum d_j 64^j, 43 windows) and one 32-entry table
 // (e + 1) 64^j G per window -- 43 mixed additions instead of 65 additions + 4 doublings.  The
 // 129 KiB table is staged once per 1 024-thread workgroup in LDS (gfx950: 160 KiB per CU); a
-// lookup reads all 32 entries of the window at wave-uniform addresses and keeps one by selects
-// (constant time, as the reference's scan, src/lookup.rs:81-102).  The accumulator starts from
-// the shift point S and S is subtracted at the end, so the incomplete addition never meets the
-// identity (the reference's own device, src/lookup.rs:196, :205).  Digits are recoded on the fly.
+// lookup goes over all 32 entries of the window at wave-uniform addresses, each lane enabled for
+// the read of the entry it wants (lds_lookup; constant time, as the reference's scan,
+// src/lookup.rs:81-102).  The accumulator is kept in XYZZ coordinates (8 M + 2 S per mixed addition,
+// curve.hip.h), starts from the shift point S and has S subtracted at the end, so the incomplete
+// addition never meets the identity (the reference's own device, src/lookup.rs:196, :205).  Digits
+// are recoded on the fly.
 template <int IN_FORM>
 __global__ void __launch_bounds__(64) k_build_wide_table(u64* wide /* [43][32][12] */, const u64* base_pt) {
     const int j = blockIdx.x, e = threadIdx.x;  // entry (e + 1) 64^j P
@@ -702,42 +737,15 @@ __global__ void __launch_bounds__(64) k_build_wide_table(u64* wide /* [43][32][1
 }
 
 template <bool GENERIC = false>
-CH_DEV Affine lds_lookup32(const u64* sub /* 32 x 12 limbs in LDS */, int d) {
-    const int neg = d < 0;
-    const int dabs = neg ? -d : d;
-    Affine t = affine_identity();
-#pragma unroll 4
-    for (int j = 1; j <= WIDE_ENTRIES; j++) {
-        const bool hit = (dabs == j);
-#pragma unroll
-        for (int l = 0; l < 6; l++) {
-            u64 vx = sub[(j - 1) * 12 + l], vy = sub[(j - 1) * 12 + 6 + l];
-            t.x.c[l] = hit ? vx : t.x.c[l];
-            t.y.c[l] = hit ? vy : t.y.c[l];
-        }
-        t.inf = hit ? false : t.inf;
-    }
-    if (GENERIC) t.inf = t.inf || affine_is_identity_encoding(t.x, t.y);
-    return affine_cond_neg(t, neg);
-}
-
-template <bool GENERIC = false>
 __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const DeviceTables* __restrict__ tab,
                                                                         const u64* __restrict__ wide,
                                                                         const u8* __restrict__ scalars, u64* __restrict__ out,
                                                                         u8* __restrict__ inf, size_t n) {
-#ifdef CH_WIDE_SCALAR  // experiment: the table read from global memory at wave-uniform addresses (scalar loads, selects on SGPR
-                       // operands), no LDS copy -- measured 136 M/s against 149 with the LDS copy (tools/gen_bench.py), not used
-    const u64* s_wide = wide;
-    const int t = threadIdx.x;
-    const Affine shift = load_affine(tab->shift);
-#else
-    __shared__ u64 s_wide[WIDE_WINDOWS * WIDE_ENTRIES * 12];
+    __shared__ __align__(16) u64 s_wide[WIDE_WINDOWS * WIDE_ENTRIES * 12];
     const int t = threadIdx.x;
     for (int w = t; w < WIDE_WINDOWS * WIDE_ENTRIES * 12; w += WIDE_BLOCK) s_wide[w] = wide[w];
     const Affine shift = load_affine(tab->shift);
     __syncthreads();
-#endif
     const size_t nround = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
     for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
         const size_t i = round * WIDE_BLOCK + t;
@@ -745,7 +753,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const D
         u64 k[4];
         load_scalar(scalars, active ? i : n - 1, k);
         const bool in_range = (k[3] >> 60) <= 7;  // the range BasePointTable::multiply covers (Q3); flagged as there
-        MJac acc = mjac_from_affine(shift);
+        XYZZ acc = xyzz_from_affine(shift);
         int carry = 0;
 #pragma unroll 1
         for (int j = 0; j < WIDE_WINDOWS; j++) {
@@ -756,12 +764,12 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const D
             k[1] = (k[1] >> 6) | (k[2] << 58);
             k[2] = (k[2] >> 6) | (k[3] << 58);
             k[3] >>= 6;
-            acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, lds_lookup32<GENERIC>(s_wide + j * (WIDE_ENTRIES * 12), d));
+            acc = xyzz_add_mixed_unchecked(acc, lds_lookup<WIDE_ENTRIES, GENERIC>(s_wide + j * (WIDE_ENTRIES * 12), d));
         }
-        acc = mjac_add_mixed_unchecked_fresh_z4<false>(acc, affine_cond_neg(shift, true));
+        acc = xyzz_add_mixed_unchecked(acc, affine_cond_neg(shift, true));
         if (active) {
             if (in_range)
-                emit_point<0>(out, inf, i, acc);
+                store_affine(out, inf, i, affine_from_xyzz(acc));
             else
                 store_rejected(out, inf, i, 12);
         }
@@ -793,28 +801,11 @@ CH_DEV void recode_radix256(const u64 k[4], i8* digits /* [32][BLOCK] */, int t)
     }
 }
 
-CH_DEV Affine lds_lookup128(const u64* tabl /* 128 x 12 limbs in LDS */, int d) {
-    const int neg = d < 0;
-    const int dabs = neg ? -d : d;  // -128 -> 128: entry 128, negated (src/lookup.rs:86-98)
-    Affine t = affine_identity();
-    for (int j = 1; j <= 128; j++) {
-        const bool hit = (dabs == j);
-#pragma unroll
-        for (int l = 0; l < 6; l++) {
-            u64 vx = tabl[(j - 1) * 12 + l], vy = tabl[(j - 1) * 12 + 6 + l];
-            t.x.c[l] = hit ? vx : t.x.c[l];
-            t.y.c[l] = hit ? vy : t.y.c[l];
-        }
-        t.inf = hit ? false : t.inf;
-    }
-    return affine_cond_neg(t, neg);
-}
-
 template <int OUT_FORM>
 __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator_lookup(const DeviceTables* __restrict__ tab,
                                                                    const u8* __restrict__ scalars, u64* __restrict__ out,
                                                                    u8* __restrict__ inf, size_t n) {
-    __shared__ u64 s_tab[128 * 12];
+    __shared__ __align__(16) u64 s_tab[128 * 12];
     __shared__ i8 s_digits[32 * BLOCK];
     const int t = threadIdx.x;
     for (int w = t; w < 128 * 12; w += BLOCK) s_tab[w] = tab->basepoint_lookup[w];
@@ -833,7 +824,7 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator_lookup
         for (int j = 31; j >= 0; j--) {
             for (int r = 0; r < 7; r++) acc = mjac_double_unchecked(acc);
             acc = Ladder<MJac>::dbl_then_add(acc);
-            acc = Ladder<MJac>::add_after_dbl(acc, lds_lookup128(s_tab, s_digits[j * BLOCK + t]));
+            acc = Ladder<MJac>::add_after_dbl(acc, lds_lookup<128>(s_tab, s_digits[j * BLOCK + t]));
         }
         acc = Ladder<MJac>::add_last(acc, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
