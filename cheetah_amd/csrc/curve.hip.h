@@ -61,20 +61,31 @@ CH_DEV Affine affine_cond_neg(const Affine& a, bool negate) {
 
 // src/curve/projective.rs:400-443.  Same field elements as the reference's sequence; its runs of doublings are
 // taken as one small-constant product (8c = 2 (4c), 8 t3^2 instead of 2 (2 t3)^2, 8 b^3 instead of 2 (2b)^2 b).
-CH_DEV Proj proj_double_unchecked(const Proj& s) {
-    Fp6 a = fp6_triple(fp6_square(s.x));
-    a = fp6_add(a, fp6_square(s.z));             // 3 x^2 + z^2
-    Fp6 b = fp6_mul(s.y, s.z);
-    Fp6 t3 = fp6_mul(s.y, b);
-    Fp6 c = fp6_mul(t3, s.x);
-    t3 = fp6_mul_small(fp6_square(t3), 8u);      // 8 (y b)^2
+template <bool INL>
+CH_DEV Proj proj_double_unchecked_impl(const Proj& s) {
+    auto mul = [](const Fp6& a, const Fp6& b) { return INL ? fp6_mul_inl(a, b) : fp6_mul(a, b); };
+    auto sqr = [](const Fp6& a) { return INL ? fp6_square_inl(a) : fp6_square(a); };
+    Fp6 a = fp6_triple(sqr(s.x));
+    a = fp6_add(a, sqr(s.z));                    // 3 x^2 + z^2
+    Fp6 b = mul(s.y, s.z);
+    Fp6 t3 = mul(s.y, b);
+    Fp6 c = mul(t3, s.x);
+    t3 = fp6_mul_small(sqr(t3), 8u);             // 8 (y b)^2
     Fp6 c4 = fp6_mul_small(c, 4u);
-    Fp6 d = fp6_sub(fp6_square(a), fp6_double(c4));  // a^2 - 8c
+    Fp6 d = fp6_sub(sqr(a), fp6_double(c4));     // a^2 - 8c
     Proj r;
-    r.x = fp6_double(fp6_mul(b, d));
-    r.y = fp6_sub(fp6_mul(a, fp6_sub(c4, d)), t3);
-    r.z = fp6_mul_small(fp6_mul(fp6_square(b), b), 8u);
+    r.x = fp6_double(mul(b, d));
+    r.y = fp6_sub(mul(a, fp6_sub(c4, d)), t3);
+    r.z = fp6_mul_small(mul(sqr(b), b), 8u);
     return r;
+}
+CH_DEV Proj proj_double_unchecked(const Proj& s) { return proj_double_unchecked_impl<false>(s); }
+// n doublings in a row (the run that opens a ladder window) with the field products inlined: one loop body of about
+// 38 KB instead of 12 n calls, whose operands and results cost ~ 29 register moves each at the call boundary.
+CH_DEV Proj proj_doubles_unchecked(Proj p, int n) {
+#pragma unroll 1
+    for (int r = 0; r < n; r++) p = proj_double_unchecked_impl<true>(p);
+    return p;
 }
 
 // src/curve/projective.rs:349-393 (same values as the unchecked form mod p:
@@ -163,30 +174,39 @@ CH_DEV Proj proj_add_mixed_unchecked(const Proj& s, const Affine& r) {
 // The same field elements are reached with fewer small-constant products: with y2 = 2y,
 // 4 y^2 = y2^2, 16 y^4 = (y2^2)^2 = 2c, z3 = y2 z, and c = 8 y^4 is half of 2c.  The products are
 // ordered so that at most six Fp6 values are live at once (the ladder kernels run at 168 VGPRs).
-template <bool WANT_Z4>
-CH_DEV MJac mjac_double_impl(const MJac& s) {
+template <bool WANT_Z4, bool INL = false>
+CH_DEV MJac mjac_double_impl(const MJac& s, bool want_z4_rt = true) {
+    auto mul = [](const Fp6& a, const Fp6& b) { return INL ? fp6_mul_inl(a, b) : fp6_mul(a, b); };
+    auto sqr = [](const Fp6& a) { return INL ? fp6_square_inl(a) : fp6_square(a); };
     MJac o;
     Fp6 y2 = fp6_double(s.y);
-    o.z = fp6_mul(y2, s.z);            // z3 = 2 y z
-    Fp6 y_sq4 = fp6_square(y2);        // 4 y^2
-    Fp6 c2 = fp6_square(y_sq4);        // 16 y^4 = 2c
-    Fp6 b = fp6_triple(fp6_square(s.x));
+    o.z = mul(y2, s.z);                // z3 = 2 y z
+    Fp6 y_sq4 = sqr(y2);               // 4 y^2
+    Fp6 c2 = sqr(y_sq4);               // 16 y^4 = 2c
+    Fp6 b = fp6_triple(sqr(s.x));
     b = fp6_add(b, s.z4);              // 3 x^2 + z^4
-    if (WANT_Z4)
-        o.z4 = fp6_mul(c2, s.z4);      // 2c z^4
-    else
-        o.z4 = s.z4;
+    o.z4 = s.z4;
+    if (WANT_Z4 && want_z4_rt) o.z4 = mul(c2, s.z4);  // 2c z^4
     Fp6 c = fp6_halve(c2);             // 8 y^4
-    Fp6 a = fp6_mul(y_sq4, s.x);       // 4 x y^2
-    o.x = fp6_square(b);
+    Fp6 a = mul(y_sq4, s.x);           // 4 x y^2
+    o.x = sqr(b);
     o.x = fp6_sub(o.x, fp6_double(a));
     o.y = fp6_sub(a, o.x);
-    o.y = fp6_mul(o.y, b);
+    o.y = mul(o.y, b);
     o.y = fp6_sub(o.y, c);
     return o;
 }
 // src/curve/jacobian.rs:1094-1128
 CH_DEV MJac mjac_double_unchecked(const MJac& s) { return mjac_double_impl<true>(s); }
+// n doublings in a row followed by an addition (the run that opens a ladder window), with the field products inlined:
+// one loop body of about 20 KB instead of 8 n - 1 calls, whose operands and results cost ~ 29 register moves each at
+// the call boundary.  The last doubling leaves z4 stale (mjac_double_unchecked_stale_z4 below); `r < n - 1` is uniform,
+// a scalar branch.
+CH_DEV MJac mjac_doubles_then_add(MJac p, int n) {
+#pragma unroll 1
+    for (int r = 0; r < n; r++) p = mjac_double_impl<true, true>(p, r < n - 1);
+    return p;
+}
 
 // The same doubling without its last product: z4 is left stale.  Only valid when the next
 // operation is mjac_add_mixed_unchecked_fresh_z4 (which rebuilds z^4 from z) or the point is

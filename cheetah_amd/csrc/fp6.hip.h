@@ -13,9 +13,12 @@
 
 // Fp6 mul / square are 410 / 305 VALU instructions each.  Inlined into every point
 // formula the ladder loop would exceed the instruction cache, so by default they
-// are real functions.  Their arguments and result cross the call as 6 x u64
-// vectors: hipcc passes those in VGPRs, whereas a second struct argument goes
-// through the stack (scratch memory).
+// are real functions (fp6_mul / fp6_square -> fp6_mul_fn / fp6_square_fn).  Their
+// arguments and result cross the call as 6 x u64 vectors: hipcc passes those in
+// VGPRs, whereas a second struct argument goes through the stack (scratch memory).
+// fp6_mul_inl / fp6_square_inl are the same products inlined at the call site: used
+// where one loop body is executed often enough to pay for its size (the run of
+// doublings that opens a ladder window, curve.hip.h).
 #ifndef CH_FP6_FN
 #define CH_FP6_FN __device__ __noinline__
 #endif
@@ -112,8 +115,7 @@ CH_DEV Fp6 fp6_from_v(fp6v v) {
     return a;
 }
 
-CH_FP6_FN fp6v fp6_mul_fn(fp6v av, fp6v bv) {
-    const Fp6 a = fp6_from_v(av), b = fp6_from_v(bv);
+CH_DEV Fp6 fp6_mul_inl(const Fp6& a, const Fp6& b) {  // the product itself, inlined where it is called
     u64 b7[6];
     b7[0] = 0;
 #pragma unroll
@@ -132,15 +134,15 @@ CH_FP6_FN fp6v fp6_mul_fn(fp6v av, fp6v bv) {
         }
         r.c[k] = acc.reduce();
     }
-    return fp6_to_v(r);
+    return r;
 }
+CH_FP6_FN fp6v fp6_mul_fn(fp6v av, fp6v bv) { return fp6_to_v(fp6_mul_inl(fp6_from_v(av), fp6_from_v(bv))); }
 CH_DEV Fp6 fp6_mul(const Fp6& a, const Fp6& b) { return fp6_from_v(fp6_mul_fn(fp6_to_v(a), fp6_to_v(b))); }
 
 // a^2 in Fp6.                                        (src/fp6.rs:838-920)
 // 21 products: cross terms use the doubled operand d_i = 2 a_i, wrapped terms
 // the scaled operand s_j = 7 a_j.
-CH_FP6_FN fp6v fp6_square_fn(fp6v av) {
-    const Fp6 a = fp6_from_v(av);
+CH_DEV Fp6 fp6_square_inl(const Fp6& a) {
     u64 d[6], s[6];
 #pragma unroll
     for (int i = 0; i < 5; i++) d[i] = fp_double(a.c[i]);
@@ -176,8 +178,9 @@ CH_FP6_FN fp6v fp6_square_fn(fp6v av) {
         }
         r.c[k] = acc.reduce();
     }
-    return fp6_to_v(r);
+    return r;
 }
+CH_FP6_FN fp6v fp6_square_fn(fp6v av) { return fp6_to_v(fp6_square_inl(fp6_from_v(av))); }
 CH_DEV Fp6 fp6_square(const Fp6& a) { return fp6_from_v(fp6_square_fn(fp6_to_v(a))); }
 
 // Frobenius maps: per-coefficient constants (src/fp6.rs:1088-1123).

@@ -126,16 +126,16 @@ CH_DEV void emit_point(u64* out, u8* inf, size_t i, const MJac& p) {
 // in.  Proj = ProjectivePoint (src/curve/projective.rs:400-443, :576-610), MJac =
 // ModifiedJacobianPoint (src/curve/jacobian.rs:1094-1128, :1146-1186).
 template <class ACC> struct Ladder;
-// dbl_then_add / add_after_dbl / add_last: the doubling that directly precedes an addition, that
-// addition, and the ladder's closing addition.  For MJac the pair skips the doubling's z4 product,
-// which the addition would overwrite anyway (it rebuilds z^4 from z), and the closing addition
-// skips z4 altogether: x, y, z -- everything a JacobianPoint has -- are untouched.
+// dbls_then_add / add_after_dbl / add_last: the run of doublings that opens a window (field products inlined,
+// curve.hip.h), the addition that follows it, and the ladder's closing addition.  For MJac the last doubling of
+// the run skips its z4 product, which the addition would overwrite anyway (it rebuilds z^4 from z), and the
+// closing addition skips z4 altogether: x, y, z -- everything a JacobianPoint has -- are untouched.
 template <> struct Ladder<Proj> {
     static CH_DEV Proj from_affine(const Affine& a) { return proj_from_affine(a); }
     static CH_DEV Proj shift16(const DeviceTables* tab) { return load_proj(tab->shift16_proj); }
     static CH_DEV Proj dbl(const Proj& p) { return proj_double_unchecked(p); }
     static CH_DEV Proj add(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
-    static CH_DEV Proj dbl_then_add(const Proj& p) { return proj_double_unchecked(p); }
+    static CH_DEV Proj dbls_then_add(const Proj& p, int n) { return proj_doubles_unchecked(p, n); }
     static CH_DEV Proj add_after_dbl(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
     static CH_DEV Proj add_last(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
 };
@@ -150,8 +150,8 @@ template <> struct Ladder<MJac> {
         return m;
     }
     static CH_DEV MJac dbl(const MJac& p) { return mjac_double_unchecked(p); }
+    static CH_DEV MJac dbls_then_add(const MJac& p, int n) { return mjac_doubles_then_add(p, n); }
     static CH_DEV MJac add(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked(p, q); }
-    static CH_DEV MJac dbl_then_add(const MJac& p) { return mjac_double_unchecked_stale_z4(p); }
     static CH_DEV MJac add_after_dbl(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<true>(p, q); }
     static CH_DEV MJac add_last(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<false>(p, q); }
 };
@@ -822,8 +822,7 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator_lookup
         __syncthreads();
         MJac acc = mjac_from_affine(shift);
         for (int j = 31; j >= 0; j--) {
-            for (int r = 0; r < 7; r++) acc = mjac_double_unchecked(acc);
-            acc = Ladder<MJac>::dbl_then_add(acc);
+            acc = Ladder<MJac>::dbls_then_add(acc, 8);
             acc = Ladder<MJac>::add_after_dbl(acc, lds_lookup<128>(s_tab, s_digits[j * BLOCK + t]));
         }
         acc = Ladder<MJac>::add_last(acc, mshift);
@@ -1018,8 +1017,7 @@ CH_DEV ACC ladder_radix16(const DeviceTables* tab, const u64* s_tab, int n_entri
     int d = s_digits[63 * BLOCK + t];
     ACC acc = Ladder<ACC>::add(Ladder<ACC>::shift16(tab), DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
     for (int j = 62; j >= 0; j--) {
-        for (int r = 0; r < 3; r++) acc = Ladder<ACC>::dbl(acc);
-        acc = Ladder<ACC>::dbl_then_add(acc);
+        acc = Ladder<ACC>::dbls_then_add(acc, 4);
         d = s_digits[j * BLOCK + t];
         acc = Ladder<ACC>::add_after_dbl(acc, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
     }
@@ -1188,10 +1186,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
         }
         ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S
         for (int w = 63; w >= 0; w--) {
-            if (w < 63) {
-                for (int r = 0; r < 3; r++) acc = Ladder<ACC>::dbl(acc);
-                acc = Ladder<ACC>::dbl_then_add(acc);
-            }
+            if (w < 63) acc = Ladder<ACC>::dbls_then_add(acc, 4);
             for (int j = 0; j < m; j++) {
                 const int d = s_dig[((size_t)j * 256 + w) * BLOCK + t];
                 const u64* tb = s_tabs + (size_t)j * ManyScratch::TAB;
