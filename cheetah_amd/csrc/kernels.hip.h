@@ -133,7 +133,7 @@ template <class ACC> struct Ladder;
 template <> struct Ladder<Proj> {
     static CH_DEV Proj from_affine(const Affine& a) { return proj_from_affine(a); }
     static CH_DEV Proj shift16(const DeviceTables* tab) { return load_proj(tab->shift16_proj); }
-    static CH_DEV Proj dbl(const Proj& p) { return proj_double_unchecked(p); }
+    static CH_DEV Proj dbl_inl(const Proj& p) { return proj_double_unchecked_impl<true>(p); }  // field products inlined
     static CH_DEV Proj add(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
     static CH_DEV Proj dbls_then_add(const Proj& p, int n) { return proj_doubles_unchecked(p, n); }
     static CH_DEV Proj add_after_dbl(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
@@ -149,7 +149,7 @@ template <> struct Ladder<MJac> {
         m.z4 = load_fp6(tab->shift16_mjac + 18);
         return m;
     }
-    static CH_DEV MJac dbl(const MJac& p) { return mjac_double_unchecked(p); }
+    static CH_DEV MJac dbl_inl(const MJac& p) { return mjac_double_impl<true, true>(p); }
     static CH_DEV MJac dbls_then_add(const MJac& p, int n) { return mjac_doubles_then_add(p, n); }
     static CH_DEV MJac add(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked(p, q); }
     static CH_DEV MJac add_after_dbl(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<true>(p, q); }
@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
                 continue;
             }
             if (can) {
-                acc = Ladder<ACC>::dbl(acc);
+                acc = Ladder<ACC>::dbl_inl(acc);
                 pd = naf4_digit(s_naf, pos, t);
                 pos--;
             }
@@ -1263,7 +1263,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
                     rescan = true;
                 }
             } else if (can) {
-                acc = Ladder<ACC>::dbl(acc);
+                acc = Ladder<ACC>::dbl_inl(acc);
                 cur = pos;
                 pos--;
                 j = 0;
