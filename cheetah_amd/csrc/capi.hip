@@ -851,7 +851,7 @@ static int32_t batch_normalize_impl(cheetah_ctx* ctx, const u64* xyz, u64* xy, u
     constexpr int CHUNK = CH_BN_CHUNK;
     size_t nchunks = (n + CHUNK - 1) / CHUNK;
     int grid = lane_grid(ctx, nchunks, CH_BN_WAVES);
-    hipLaunchKernelGGL((k_batch_normalize<JAC, CHUNK, CH_BN_NLDS>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
+    hipLaunchKernelGGL((k_batch_normalize<JAC>), dim3(grid), dim3(BLOCK), 0, ctx->stream, xyz, xy, inf, n);
     HIP_TRY(ctx, hipGetLastError());
     return CHEETAH_OK;
 }

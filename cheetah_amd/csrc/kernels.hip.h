@@ -30,7 +30,7 @@ constexpr int BLOCK = 256;
 #define CH_MANY_WAVES 2
 #endif
 #ifndef CH_BN_WAVES
-#define CH_BN_WAVES 2
+#define CH_BN_WAVES 3
 #endif
 
 // ---------------------------------------------------------------------------
@@ -373,80 +373,57 @@ __global__ void __launch_bounds__(BLOCK) k_fp_op(int op, const u64* __restrict__
 // tile + t, tile + BLOCK + t, ..., so at every step the workgroup touches BLOCK
 // consecutive 144-byte records with 16-byte accesses -- each 128-byte line is
 // fetched from HBM once -- instead of one record per 1 152 bytes.
-// Measured (MI355X, 2^24 Jacobian points, tools/bn_bench.py, profiles/r02_bn_variants.txt): what the kernel lacked was
-// not occupancy but loads in flight.  Every step's operands are now requested one step ahead of their use (the next
-// point's z in the forward pass; x, y, z of point j - 1 while point j is computed), which needs ~60 more VGPRs than
-// three waves per SIMD leave, so the kernel is compiled for two waves per SIMD: 8.0 G points/s against 7.35 before.
-// NLDS > 0 keeps the first NLDS prefix products of a chunk in LDS ([slot][limb][lane], 8-byte accesses, conflict
-// free) instead of registers; every (CHUNK, NLDS, waves) combination that does not spill measured 7.5 - 8.0 G/s
-// (chunk 4 - 12: the Fp6 inversion per chunk is not what bounds it), so the default is the simplest: 8, 0, 2.
-// Second series (same file): the trivial prefix (1) is no longer kept or multiplied (3 products fewer per chunk), the
-// forward pass requests z CH_BN_AHEAD steps ahead, and with the prefixes in LDS the kernel also runs at 3 and 4 waves
-// per SIMD without the backward prefetch (CH_BN_PREFETCH 0): 2.08 - 2.12 ms for every shape again.  tools/mem_pattern.hip
-// shows why: moving the records with no arithmetic at all takes 0.87 ms in this access pattern (0.77 ms with
-// wave-contiguous accesses), the VALU work alone is ~1.5 ms at the ladder kernels' issue rate, and the kernel needs
-// 70 % of the memory pipeline's capacity while it computes -- the two overlap, but not perfectly (2.1 ms lies between
-// max = 1.5 and sum = 2.4).  The arithmetic alone, measured with -DCH_BN_NOMEM (no loads, stores elided), takes 1.80 ms at
-// this shape and 1.75 ms at (4, 3, 4): the kernel runs at 86 % of its own compute floor, whatever the occupancy.
-// A build that requested every record straight into LDS two steps ahead (global_load_lds_dwordx4, a ring of 18 KiB per
-// wave, vmcnt counted by hand; results bit-identical) measured 2.15 ms against 2.06 on the same box: deeper prefetch is
-// not what is missing either, and that kernel was not kept.
+// Measured (MI355X, 2^24 Jacobian points, tools/bn_bench.py, profiles/r02_bn_variants.txt).  The first form of this
+// kernel was fully unrolled over the chunk with the prefixes in registers and every field product a call: 7.35 G
+// points/s, 8.0 once each step's operands were requested ahead of their use; chunk sizes 4 - 12, prefixes in LDS,
+// 2 - 4 waves per SIMD, deeper prefetch (global_load_lds_dwordx4 rings) all measured the same 2.06 - 2.12 ms, against
+// 1.80 ms for the arithmetic alone (-DCH_BN_NOMEM) and 0.87 ms for the records alone (tools/mem_pattern.hip).
+// What moved it was the instruction count: both passes are now ROLLED loops, one body each, with the field products
+// inlined (fp6_mul_inl: no calls, no operand marshalling; the unrolled form inlined would be ~150 KB of code).  A
+// rolled loop cannot index a register array, so the prefix products before points 2 .. CHUNK - 1 live in LDS
+// ([slot][limb][lane], 8-byte accesses, conflict free; 48 KiB per workgroup) and the one before point 1 in registers;
+// the next point's operands are still requested one step ahead (z two steps ahead in the forward pass).  Shapes
+// measured on one box (default before: 2.158 ms): chunk 6 at 3 waves per SIMD 1.978 ms (kept), chunk 7 with two
+// register prefixes at 3 waves 1.982, chunk 8 at 2 waves 1.993 - 2.02, chunk 5 - 6 at 4 waves 2.13.
 #ifndef CH_BN_CHUNK
-#define CH_BN_CHUNK 8
+#define CH_BN_CHUNK 6
 #endif
-#ifndef CH_BN_NLDS
-#define CH_BN_NLDS 0
+#ifndef CH_BN_NREG
+#define CH_BN_NREG 1
 #endif
-#ifndef CH_BN_AHEAD
-#define CH_BN_AHEAD 2
-#endif
-#ifndef CH_BN_PREFETCH
-#define CH_BN_PREFETCH 1
-#endif
-template <int JAC, int CHUNK, int NLDS>
+template <int JAC>
 __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
-                                                              u8* __restrict__ inf, size_t n) {
-    // prefix[j] = product of the lane's non-zero z's before its point j, j = 1 .. CHUNK - 1 (prefix[0] = 1 is not kept):
-    // the first NLDS of them in LDS ([slot][limb][lane]), the others in registers
-    __shared__ u64 s_prefix[(NLDS > 0 ? NLDS : 1) * 6 * BLOCK];
+                                                                     u8* __restrict__ inf, size_t n) {
+    constexpr int CHUNK = CH_BN_CHUNK;
+    constexpr int NREG = CH_BN_NREG;  // prefixes before points 1 .. NREG in registers, the others in LDS
+    __shared__ u64 s_prefix[(CHUNK - 1 - NREG) * 6 * BLOCK];
     const int t = threadIdx.x;
     const size_t tile_pts = (size_t)BLOCK * CHUNK;
     const size_t ntiles = (n + tile_pts - 1) / tile_pts;
+    auto load_z = [&](size_t e) { return e < n ? load_fp6_vec(xyz + 18 * e + 12) : fp6_zero(); };
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t e0 = tile * tile_pts + t;
-        Fp6 prefix[CHUNK - 1 > NLDS ? CHUNK - 1 - NLDS : 1];
-        Fp6 acc = fp6_one();
-        Fp6 zq[CH_BN_AHEAD];  // the z's of the next CH_BN_AHEAD points, requested that many steps before their use
+        Fp6 z = load_z(e0), za = load_z(e0 + BLOCK), zb = load_z(e0 + 2 * (size_t)BLOCK);
+        Fp6 acc = fp6_select(z, fp6_one(), fp6_is_zero(z));
+        const Fp6 pre1 = acc;
+        Fp6 pre2 = acc;
+#pragma unroll 1
+        for (int j = 1; j < CHUNK; j++) {
+            z = za;
+            za = zb;
+            zb = j + 2 < CHUNK ? load_z(e0 + (size_t)(j + 2) * BLOCK) : fp6_zero();
+            if (NREG == 2 && j == 2) pre2 = acc;
+            if (j > NREG) {
 #pragma unroll
-        for (int d = 0; d < CH_BN_AHEAD; d++) {
-            const size_t en = e0 + (size_t)d * BLOCK;
-            zq[d] = (d < CHUNK && en < n) ? load_fp6_vec(xyz + 18 * en + 12) : fp6_zero();
-        }
-#pragma unroll
-        for (int j = 0; j < CHUNK; j++) {
-            const Fp6 z = zq[j % CH_BN_AHEAD];  // a point beyond n reads as z = 0: skipped like an identity, never stored
-            if (j + CH_BN_AHEAD < CHUNK) {
-                const size_t en = e0 + (size_t)(j + CH_BN_AHEAD) * BLOCK;
-                zq[j % CH_BN_AHEAD] = en < n ? load_fp6_vec(xyz + 18 * en + 12) : fp6_zero();
+                for (int l = 0; l < 6; l++) s_prefix[((j - 1 - NREG) * 6 + l) * BLOCK + t] = acc.c[l];
             }
-            if (j >= 1 && j - 1 < NLDS) {
-#pragma unroll
-                for (int l = 0; l < 6; l++) s_prefix[((j - 1) * 6 + l) * BLOCK + t] = acc.c[l];
-            } else if (j >= 1) {
-                prefix[j - 1 - NLDS] = acc;
-            }
-            if (j == 0) {
-                acc = fp6_select(z, acc, fp6_is_zero(z));
-            } else {
-                Fp6 m = fp6_mul(acc, z);
-                acc = fp6_select(m, acc, fp6_is_zero(z));
-            }
+            const Fp6 m = fp6_mul_inl(acc, z);
+            acc = fp6_select(m, acc, fp6_is_zero(z));
         }
         bool some;
         acc = fp6_invert(acc, &some);
-        // backward pass; with CH_BN_PREFETCH the operands of point j - 1 are requested while point j is computed
         Fp6 nx, ny, nz;
-        if (CH_BN_PREFETCH) {
+        {
             const size_t e = e0 + (size_t)(CHUNK - 1) * BLOCK;
             const bool in = e < n;
             const u64* p = xyz + 18 * (in ? e : 0);
@@ -454,53 +431,39 @@ __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u6
             ny = load_fp6_vec(p + 6);
             nz = in ? load_fp6_vec(p + 12) : fp6_zero();
         }
-#pragma unroll
+#pragma unroll 1
         for (int j = CHUNK - 1; j >= 0; j--) {
             const size_t e = e0 + (size_t)j * BLOCK;
-            Fp6 x, y, z;
-            if (CH_BN_PREFETCH) {
-                x = nx;
-                y = ny;
-                z = nz;
-                if (j > 0) {
-                    const size_t ep = e - BLOCK;
-                    const bool in = ep < n;
-                    const u64* p = xyz + 18 * (in ? ep : 0);
-                    nx = load_fp6_vec(p);
-                    ny = load_fp6_vec(p + 6);
-                    nz = in ? load_fp6_vec(p + 12) : fp6_zero();
-                }
-            } else {
-                const bool in = e < n;
-                const u64* p = xyz + 18 * (in ? e : 0);
-                z = in ? load_fp6_vec(p + 12) : fp6_zero();
-                x = load_fp6_vec(p);
-                y = load_fp6_vec(p + 6);
+            const Fp6 x = nx, y = ny;
+            z = nz;
+            if (j > 0) {
+                const size_t ep = e - BLOCK;
+                const bool in = ep < n;
+                const u64* p = xyz + 18 * (in ? ep : 0);
+                nx = load_fp6_vec(p);
+                ny = load_fp6_vec(p + 6);
+                nz = in ? load_fp6_vec(p + 12) : fp6_zero();
             }
             const bool skip = fp6_is_zero(z);
-            Fp6 zi;  // 1 / z_j
-            if (j == 0) {
-                zi = acc;
-            } else {
-                Fp6 pre;
-                if (j - 1 < NLDS) {
+            Fp6 zi = acc;  // 1 / z_j
+            if (j > 0) {
+                Fp6 pre = (NREG == 2 && j == 2) ? pre2 : pre1;
+                if (j > NREG) {
 #pragma unroll
-                    for (int l = 0; l < 6; l++) pre.c[l] = s_prefix[((j - 1) * 6 + l) * BLOCK + t];
-                } else {
-                    pre = prefix[j - 1 - NLDS];
+                    for (int l = 0; l < 6; l++) pre.c[l] = s_prefix[((j - 1 - NREG) * 6 + l) * BLOCK + t];
                 }
-                zi = fp6_mul(pre, acc);
-                Fp6 m = fp6_mul(acc, z);
+                zi = fp6_mul_inl(pre, acc);
+                const Fp6 m = fp6_mul_inl(acc, z);
                 acc = fp6_select(m, acc, skip);
             }
             Affine o;
             if (JAC) {
-                Fp6 zi2 = fp6_square(zi);
-                o.x = fp6_mul(x, zi2);
-                o.y = fp6_mul(fp6_mul(y, zi2), zi);
+                const Fp6 zi2 = fp6_square_inl(zi);
+                o.x = fp6_mul_inl(x, zi2);
+                o.y = fp6_mul_inl(fp6_mul_inl(y, zi2), zi);
             } else {
-                o.x = fp6_mul(x, zi);
-                o.y = fp6_mul(y, zi);
+                o.x = fp6_mul_inl(x, zi);
+                o.y = fp6_mul_inl(y, zi);
             }
             o.inf = false;
             if (skip) o = affine_identity();

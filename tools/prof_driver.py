@@ -26,7 +26,7 @@ vt, vinf = eng.multiply_vartime_batch(pts, k, AFFINE, AFFINE)  # k_multiply_vart
 jac, jinf = eng.multiply_batch(pts, k, AFFINE, JACOBIAN)
 nb = min(1 << 24, n * 16)
 big = jac.repeat(nb // n, 1).contiguous()
-xy, binf = eng.batch_normalize(big, JACOBIAN)              # k_batch_normalize<1,8>
+xy, binf = eng.batch_normalize(big, JACOBIAN)              # k_batch_normalize<1>
 nf = 1 << lf
 a, b = eng.synth_fp6(1, nf, 0), eng.synth_fp6(1, nf, nf)
 for _ in range(3):
