@@ -144,25 +144,28 @@ CH_DEV Proj proj_add(const Proj& s, const Proj& r) {
 }
 
 // src/curve/projective.rs:576-610 (incomplete; returns s when r is the identity)
+template <bool INL = false>
 CH_DEV Proj proj_add_mixed_unchecked(const Proj& s, const Affine& r) {
-    Fp6 t0 = fp6_mul(r.y, s.z);
+    auto mul = [](const Fp6& a, const Fp6& b) { return INL ? fp6_mul_inl(a, b) : fp6_mul(a, b); };
+    auto sqr = [](const Fp6& a) { return INL ? fp6_square_inl(a) : fp6_square(a); };
+    Fp6 t0 = mul(r.y, s.z);
     t0 = fp6_sub(t0, s.y);
-    Fp6 t1 = fp6_mul(r.x, s.z);
+    Fp6 t1 = mul(r.x, s.z);
     t1 = fp6_sub(t1, s.x);
-    Fp6 t2 = fp6_square(t0);
-    t2 = fp6_mul(t2, s.z);
-    Fp6 t3 = fp6_square(t1);
-    Fp6 t4 = fp6_mul(t1, t3);
+    Fp6 t2 = sqr(t0);
+    t2 = mul(t2, s.z);
+    Fp6 t3 = sqr(t1);
+    Fp6 t4 = mul(t1, t3);
     t2 = fp6_sub(t2, t4);
-    Fp6 t5 = fp6_mul(t3, s.x);
+    Fp6 t5 = mul(t3, s.x);
     Fp6 t6 = fp6_double(t5);
     t2 = fp6_sub(t2, t6);
-    Fp6 x3 = fp6_mul(t1, t2);
+    Fp6 x3 = mul(t1, t2);
     Fp6 y3 = fp6_sub(t5, t2);
-    y3 = fp6_mul(y3, t0);
-    Fp6 t7 = fp6_mul(t4, s.y);
+    y3 = mul(y3, t0);
+    Fp6 t7 = mul(t4, s.y);
     y3 = fp6_sub(y3, t7);
-    Fp6 z3 = fp6_mul(t4, s.z);
+    Fp6 z3 = mul(t4, s.z);
     Proj o;
     o.x = fp6_select(x3, s.x, r.inf);
     o.y = fp6_select(y3, s.y, r.inf);
@@ -218,36 +221,38 @@ CH_DEV MJac mjac_double_unchecked_stale_z4(const MJac& s) { return mjac_double_i
 // returns self there, whose z4 = z^4 by construction); otherwise the reference's own selection.
 // WANT_Z4 = false: the result is emitted, z4 is not needed.  Same products as the reference, ordered
 // for short live ranges; each output is selected as soon as it is complete.
-template <bool FRESH_Z4, bool WANT_Z4>
+template <bool FRESH_Z4, bool WANT_Z4, bool INL = false>
 CH_DEV MJac mjac_add_mixed_impl(const MJac& s, const Affine& r) {
+    auto mul = [](const Fp6& a, const Fp6& b) { return INL ? fp6_mul_inl(a, b) : fp6_mul(a, b); };
+    auto sqr = [](const Fp6& a) { return INL ? fp6_square_inl(a) : fp6_square(a); };
     MJac o;
-    Fp6 z1_sq = fp6_square(s.z);
-    Fp6 b = fp6_mul(r.x, z1_sq);
-    Fp6 d = fp6_mul(s.z, z1_sq);
-    d = fp6_mul(d, r.y);
+    Fp6 z1_sq = sqr(s.z);
+    Fp6 b = mul(r.x, z1_sq);
+    Fp6 d = mul(s.z, z1_sq);
+    d = mul(d, r.y);
     Fp6 e = fp6_sub(b, s.x);
     Fp6 f = fp6_sub(d, s.y);
-    Fp6 e_sq = fp6_square(e);
-    Fp6 z3 = fp6_mul(s.z, e);
+    Fp6 e_sq = sqr(e);
+    Fp6 z3 = mul(s.z, e);
     o.z = fp6_select(z3, s.z, r.inf);
     if (!FRESH_Z4) {
-        Fp6 z34 = fp6_square(fp6_square(z3));
+        Fp6 z34 = sqr(sqr(z3));
         o.z4 = fp6_select(z34, s.z4, r.inf);
     }
-    Fp6 e_sq_e = fp6_mul(e, e_sq);
-    Fp6 x_e_sq = fp6_mul(s.x, e_sq);
-    Fp6 x3 = fp6_square(f);
+    Fp6 e_sq_e = mul(e, e_sq);
+    Fp6 x_e_sq = mul(s.x, e_sq);
+    Fp6 x3 = sqr(f);
     x3 = fp6_sub(x3, e_sq_e);
     x3 = fp6_sub(x3, fp6_double(x_e_sq));
     Fp6 y3 = fp6_sub(x_e_sq, x3);
     o.x = fp6_select(x3, s.x, r.inf);
-    Fp6 t3 = fp6_mul(s.y, e_sq_e);
-    y3 = fp6_mul(y3, f);
+    Fp6 t3 = mul(s.y, e_sq_e);
+    y3 = mul(y3, f);
     y3 = fp6_sub(y3, t3);
     o.y = fp6_select(y3, s.y, r.inf);
     if (FRESH_Z4) {
         if (WANT_Z4)
-            o.z4 = fp6_square(fp6_square(o.z));
+            o.z4 = sqr(sqr(o.z));
         else
             o.z4 = s.z4;
     }
@@ -274,21 +279,24 @@ CH_DEV XYZZ xyzz_from_affine(const Affine& a) {  // a is not the identity
     o.zzz = fp6_one();
     return o;
 }
+template <bool INL = false>
 CH_DEV XYZZ xyzz_add_mixed_unchecked(const XYZZ& s, const Affine& r) {
+    auto mul = [](const Fp6& a, const Fp6& b) { return INL ? fp6_mul_inl(a, b) : fp6_mul(a, b); };
+    auto sqr = [](const Fp6& a) { return INL ? fp6_square_inl(a) : fp6_square(a); };
     XYZZ o;
-    Fp6 p = fp6_sub(fp6_mul(r.x, s.zz), s.x);
-    Fp6 rr = fp6_sub(fp6_mul(r.y, s.zzz), s.y);
-    Fp6 pp = fp6_square(p);
-    Fp6 ppp = fp6_mul(p, pp);
-    o.zz = fp6_select(fp6_mul(s.zz, pp), s.zz, r.inf);
-    o.zzz = fp6_select(fp6_mul(s.zzz, ppp), s.zzz, r.inf);
-    Fp6 q = fp6_mul(s.x, pp);
-    Fp6 x3 = fp6_square(rr);
+    Fp6 p = fp6_sub(mul(r.x, s.zz), s.x);
+    Fp6 rr = fp6_sub(mul(r.y, s.zzz), s.y);
+    Fp6 pp = sqr(p);
+    Fp6 ppp = mul(p, pp);
+    o.zz = fp6_select(mul(s.zz, pp), s.zz, r.inf);
+    o.zzz = fp6_select(mul(s.zzz, ppp), s.zzz, r.inf);
+    Fp6 q = mul(s.x, pp);
+    Fp6 x3 = sqr(rr);
     x3 = fp6_sub(x3, ppp);
     x3 = fp6_sub(x3, fp6_double(q));
-    Fp6 y3 = fp6_mul(rr, fp6_sub(q, x3));
+    Fp6 y3 = mul(rr, fp6_sub(q, x3));
     o.x = fp6_select(x3, s.x, r.inf);
-    y3 = fp6_sub(y3, fp6_mul(s.y, ppp));
+    y3 = fp6_sub(y3, mul(s.y, ppp));
     o.y = fp6_select(y3, s.y, r.inf);
     return o;
 }

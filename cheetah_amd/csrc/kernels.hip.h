@@ -138,6 +138,7 @@ template <> struct Ladder<Proj> {
     static CH_DEV Proj dbls_then_add(const Proj& p, int n) { return proj_doubles_unchecked(p, n); }
     static CH_DEV Proj add_after_dbl(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
     static CH_DEV Proj add_last(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
+    static CH_DEV Proj add_inl(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked<true>(p, q); }
 };
 template <> struct Ladder<MJac> {
     static CH_DEV MJac from_affine(const Affine& a) { return mjac_from_affine(a); }
@@ -154,6 +155,8 @@ template <> struct Ladder<MJac> {
     static CH_DEV MJac add(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked(p, q); }
     static CH_DEV MJac add_after_dbl(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<true>(p, q); }
     static CH_DEV MJac add_last(const MJac& p, const Affine& q) { return mjac_add_mixed_unchecked_fresh_z4<false>(p, q); }
+    // any addition, z^4 rebuilt from the z returned, field products inlined
+    static CH_DEV MJac add_inl(const MJac& p, const Affine& q) { return mjac_add_mixed_impl<true, true, true>(p, q); }
 };
 
 // (0, 1) is the affine encoding of the identity (src/curve/affine.rs:224-230); it is not a point of the curve
@@ -658,9 +661,16 @@ __global__ void __launch_bounds__(BLOCK, CH_GEN_WAVES) k_mul_by_generator(const 
         __syncthreads();
         const bool in_range = (k[3] >> 60) <= 7;  // LookupTable<8> covers the top digit only then (Q3)
         Proj acc = proj_from_affine(shift);
-        for (int j = 1; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup<8, GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
-        for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
-        for (int j = 0; j < 64; j += 2) acc = proj_add_mixed_unchecked(acc, lds_lookup<8, GENERIC>(s_tab + (j / 2) * 96, s_digits[j * BLOCK + t]));
+        // the odd digits, four doublings, the even digits (src/lookup.rs:197-204): one loop body for the 64 additions,
+        // its field products inlined
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+            for (int jj = 0; jj < 32; jj++)
+                acc = proj_add_mixed_unchecked<true>(acc, lds_lookup<8, GENERIC>(s_tab + jj * 96, s_digits[(2 * jj + 1 - pass) * BLOCK + t]));
+            if (pass == 0)
+                for (int r = 0; r < 4; r++) acc = proj_double_unchecked(acc);
+        }
         acc = proj_add_mixed_unchecked(acc, mshift4);
         if (active) {
             if (in_range)
@@ -727,7 +737,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 4) k_mul_by_generator_wide(const D
             k[1] = (k[1] >> 6) | (k[2] << 58);
             k[2] = (k[2] >> 6) | (k[3] << 58);
             k[3] >>= 6;
-            acc = xyzz_add_mixed_unchecked(acc, lds_lookup<WIDE_ENTRIES, GENERIC>(s_wide + j * (WIDE_ENTRIES * 12), d));
+            acc = xyzz_add_mixed_unchecked<true>(acc, lds_lookup<WIDE_ENTRIES, GENERIC>(s_wide + j * (WIDE_ENTRIES * 12), d));  // products inlined
         }
         acc = xyzz_add_mixed_unchecked(acc, affine_cond_neg(shift, true));
         if (active) {
@@ -1154,7 +1164,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
                 const int d = s_dig[((size_t)j * 256 + w) * BLOCK + t];
                 const u64* tb = s_tabs + (size_t)j * ManyScratch::TAB;
                 const Affine q = DIRECT ? index_lookup(tb, s_ident[j * BLOCK + t], d, t) : scan_lookup(tb, n_entries, s_ident[j * BLOCK + t], d, t);
-                acc = (j == 0 && w < 63) ? Ladder<ACC>::add_after_dbl(acc, q) : Ladder<ACC>::add(acc, q);
+                acc = Ladder<ACC>::add_inl(acc, q);  // one loop body for the m additions of a window
             }
         }
         acc = Ladder<ACC>::add_last(acc, mshift);
