@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run, GPU against the oracle: random entry point, forms, batch size, with special points
 (identities in every encoding, G, -G, repeated points) and special scalars (0, 1, q - 1, q, 2^255 - 1, bit 255 set) mixed
-into seeded batches.  usage: tests/fuzz_gpu.py <seconds> [seed].  Prints one line per mismatch and a summary; exit 1 on
+into seeded batches.  usage: tests/fuzz_gpu.py <seconds> [seed] [max batch size, default 1500].  Prints one line per mismatch and a summary; exit 1 on
 any mismatch.  Not a test (no fixed duration): tests/ holds the deterministic cases this found or could find."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +14,7 @@ P = 0xFFFFFFFF00000001
 Q = synth.Q
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
 rng = np.random.default_rng(seed)
 ora.build()
 eng = Engine(0)
@@ -99,7 +100,7 @@ while time.time() < t_end:
     if time.time() > t_note:
         print("... %d runs, %d findings" % (runs, bad), flush=True)
         t_note = time.time() + 30
-    n = int(rng.integers(1, 1500))
+    n = int(rng.integers(1, max_n))
     case = int(rng.integers(0, 12))
     in_form, out_form = pick_forms()
     aff = affine_points(n)
@@ -206,6 +207,6 @@ while time.time() < t_end:
     except Exception as e:  # an error code where the oracle has an answer is a finding too
         print("ERROR %s n=%d host=%s: %s" % (name, n, use_host, e), flush=True)
         bad += 1
-print("fuzz: %d runs, %d findings, seed %d, %.0f s" % (runs, bad, seed, budget), flush=True)
+print("fuzz: %d runs, %d findings, seed %d, %.0f s, batches up to %d" % (runs, bad, seed, budget, max_n), flush=True)
 eng.close()
 sys.exit(1 if bad else 0)
