@@ -203,18 +203,14 @@ CH_DEV MJac mjac_double_impl(const MJac& s, bool want_z4_rt = true) {
 CH_DEV MJac mjac_double_unchecked(const MJac& s) { return mjac_double_impl<true>(s); }
 // n doublings in a row followed by an addition (the run that opens a ladder window), with the field products inlined:
 // one loop body of about 20 KB instead of 8 n - 1 calls, whose operands and results cost ~ 29 register moves each at
-// the call boundary.  The last doubling leaves z4 stale (mjac_double_unchecked_stale_z4 below); `r < n - 1` is uniform,
-// a scalar branch.
+// the call boundary.  The last doubling skips its z4 product (`r < n - 1` is uniform, a scalar branch) and leaves z4
+// stale: only valid when the next operation is mjac_add_mixed_unchecked_fresh_z4, which rebuilds z^4 from the z it
+// returns, or the point is emitted (a JacobianPoint has no z4, src/curve/jacobian.rs:118-126).  x, y, z are unchanged.
 CH_DEV MJac mjac_doubles_then_add(MJac p, int n) {
 #pragma unroll 1
     for (int r = 0; r < n; r++) p = mjac_double_impl<true, true>(p, r < n - 1);
     return p;
 }
-
-// The same doubling without its last product: z4 is left stale.  Only valid when the next
-// operation is mjac_add_mixed_unchecked_fresh_z4 (which rebuilds z^4 from z) or the point is
-// emitted (a JacobianPoint has no z4, src/curve/jacobian.rs:118-126).  x, y, z are unchanged.
-CH_DEV MJac mjac_double_unchecked_stale_z4(const MJac& s) { return mjac_double_impl<false>(s); }
 
 // src/curve/jacobian.rs:1146-1186.  FRESH_Z4: the accumulator's z4 is stale (see above) and z^4 is
 // rebuilt from the z that is returned, so it is right for the identity operand too (the reference
