@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--cpu-sample-log2", type=int, default=14, help="CPU baseline sample = 2^k multiplications per core")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Fp6 / batch_normalize roofline measurements")
+    ap.add_argument("--launch-rounds", type=int, default=0,
+                    help="rounds of the resident grid per ladder launch (0: 16 on one GPU, where no collective waits for a "
+                         "launch boundary; the library's default 2 otherwise)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="CUs' worth of workgroup slots the persistent launches leave free for the RCCL kernel (--gpus > 1)")
     ap.add_argument("--rccl-at-one", action="store_true",
@@ -310,6 +313,8 @@ def main():
     eng = Engine(local_rank)
     if dist_on and args.reserve_cus:
         eng.set_reserved_cus(args.reserve_cus)
+    launch_rounds = args.launch_rounds or (2 if dist_on else 16)
+    eng.set_launch_rounds(launch_rounds)
     n = 1 << args.log2n
     chunks = args.chunks or (8 if dist_on else 1)
     s, plan = shard_plan(n, world, chunks)
@@ -423,7 +428,7 @@ def main():
             "config": {"workload": "2^%d variable-base constant-time scalar mults (AffinePoint::multiply = JacobianPoint::multiply ladder), affine in/out, "
                                    "sharded over %d GPU(s), RCCL all-gather of results (BASELINE config 5)" % (args.log2n, world),
                        "n": n, "per_gpu": n // world, "allgather_chunks": chunks, "parallelism": "shard%d" % world,
-                       "reserved_cus": args.reserve_cus if dist_on else 0},
+                       "reserved_cus": args.reserve_cus if dist_on else 0, "launch_rounds": launch_rounds},
             "checksum": "%016x" % checksum,
             "identities": n_inf,
             "ranks_seen": int(ones.item()),

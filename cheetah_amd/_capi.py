@@ -52,6 +52,7 @@ SIGNATURES = {
     "cheetah_ctx_use_own_stream": (C.c_int32, [_vp]),
     "cheetah_ctx_synchronize": (C.c_int32, [_vp]),
     "cheetah_ctx_set_reserved_cus": (C.c_int32, [_vp, _i]),
+    "cheetah_ctx_set_launch_rounds": (C.c_int32, [_vp, _i]),
     "cheetah_last_error": (C.c_char_p, [_vp]),
     "cheetah_version": (C.c_char_p, []),
     "cheetah_fp6_mul_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),

@@ -57,6 +57,7 @@ struct cheetah_ctx {
     int num_cus = 0;
     bool force_reference_schedule = false;  // cheetah_debug_set_reference_schedule: no composed fast paths
     int reserved_cus = 0;  // CUs' worth of workgroup slots the persistent launches leave free (cheetah_ctx_set_reserved_cus)
+    int launch_rounds = 2;  // rounds of the resident grid one ladder launch covers (cheetah_ctx_set_launch_rounds)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
     // host-pointer pipeline: copy streams, per-buffer-set events, staging buffers (two sets)
     hipStream_t s_in = nullptr, s_out = nullptr;
@@ -318,6 +319,14 @@ extern "C" int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx* ctx, int cus) {
     return CHEETAH_OK;
 }
 
+extern "C" int32_t cheetah_ctx_set_launch_rounds(cheetah_ctx* ctx, int rounds) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (rounds < 1 || rounds > 256) return fail(ctx, CHEETAH_ERR_INVALID, "launch rounds must be in [1, 256]");
+    ctx->launch_rounds = rounds;
+    for (cheetah_ctx* s : ctx->subs) s->launch_rounds = rounds;
+    return CHEETAH_OK;
+}
+
 // Grid for the compute-bound per-lane kernels: enough 256-thread workgroups to
 // fill every CU at the occupancy the kernel's registers allow, no more than the
 // work needs.  The kernels grid-stride over the rest.
@@ -333,7 +342,6 @@ static int ew_grid(const cheetah_ctx* c, size_t n) {
     return (int)(tiles < cap ? tiles : cap);
 }
 
-constexpr int ROUNDS_PER_LAUNCH = 2;
 
 // The arena is sized at creation for the single-scalar ladders; only the multi-scalar kernels with many points per
 // group need more, and then only the first time: the context's stream is drained before the old arena is released.
@@ -906,7 +914,7 @@ static int32_t fixed_base_impl(cheetah_ctx* ctx, const u64* comb, const u64* wid
         size_t want = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
         const size_t cus_w = (size_t)(ctx->num_cus - ctx->reserved_cus);
         int grid_w = (int)(want < cus_w ? want : cus_w);
-        const size_t per_launch_w = (size_t)grid_w * WIDE_BLOCK * ROUNDS_PER_LAUNCH * 4;
+        const size_t per_launch_w = (size_t)grid_w * WIDE_BLOCK * ctx->launch_rounds * 4;
         for (size_t off = 0; off < n; off += per_launch_w) {
             const size_t cnt = n - off < per_launch_w ? n - off : per_launch_w;
             hipLaunchKernelGGL((k_mul_by_generator_wide<GENERIC>), dim3(grid_w), dim3(WIDE_BLOCK), 0, ctx->stream, ctx->tables, wide,
@@ -916,7 +924,7 @@ static int32_t fixed_base_impl(cheetah_ctx* ctx, const u64* comb, const u64* wid
         return CHEETAH_OK;
     }
     int grid = lane_grid(ctx, n, CH_GEN_WAVES);
-    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH * 4;  // bounded launches, as in multiply_impl
+    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds * 4;  // bounded launches, as in multiply_impl
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u8* sc_o = scalars32 + off * 32;
@@ -1092,11 +1100,11 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
         arena = ctx->scratch;
     }
     const int grid = (VARTIME && !direct) ? grid_vt : grid_ct;
-    // One launch covers at most ROUNDS_PER_LAUNCH rounds of the resident grid (18 ms of work at 4 workgroups per CU).
+    // One launch covers at most ctx->launch_rounds rounds of the resident grid (default 2: 17 ms of work at 4 workgroups per CU).
     // The workgroups are persistent within a launch and fill every CU, so a kernel on another stream (the RCCL
     // all-gather of the previous chunk) can only get CU slots at a launch boundary: bounding the launch bounds its wait.
     const size_t in_w = form_limbs(in_form), out_w = form_limbs(out_form);
-    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;
+    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds;
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u64* pts_o = pts + off * in_w;
@@ -1239,7 +1247,7 @@ static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form,
     const size_t wpb = ManyScratch::words(m, ns);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * wpb)) return rc;
     const size_t in_w = form_limbs(in_form), out_w = form_limbs(out_form);
-    size_t rounds = ROUNDS_PER_LAUNCH / (size_t)m;
+    size_t rounds = (size_t)ctx->launch_rounds / (size_t)m;
     if (rounds == 0) rounds = 1;
     const size_t per_launch = (size_t)grid * BLOCK * rounds;
     for (size_t off = 0; off < n_groups; off += per_launch) {
@@ -1337,7 +1345,7 @@ static int32_t fixed_scalar_impl(cheetah_ctx* ctx, const u64* pts, int in_form, 
     int grid = lane_grid(ctx, n, CH_VT_WAVES);
     if (int32_t rc = ensure_scratch(ctx, (size_t)grid * LaneScratch::WORDS_PER_BLOCK)) return rc;
     const size_t in_w = form_limbs(in_form), out_w = out_form == CHEETAH_AFFINE ? 12 : 18;
-    const size_t per_launch = (size_t)grid * BLOCK * ROUNDS_PER_LAUNCH;
+    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds;
     const bool proj = in_form == CHEETAH_PROJECTIVE || out_form == CHEETAH_PROJECTIVE;
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
@@ -1765,7 +1773,7 @@ extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n,
     if (!ctx) return CHEETAH_ERR_INVALID;
     if (!units) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     const int waves = (vartime && out_form != CHEETAH_AFFINE) ? CH_VT_WAVES : CH_CT_WAVES;
-    const size_t per_launch = (size_t)lane_grid(ctx, n ? n : 1, waves) * BLOCK * ROUNDS_PER_LAUNCH;
+    const size_t per_launch = (size_t)lane_grid(ctx, n ? n : 1, waves) * BLOCK * ctx->launch_rounds;
     *units = n < per_launch ? n : per_launch;
     return CHEETAH_OK;
 }

@@ -626,6 +626,11 @@ class Engine:
         another stream); 0 = none."""
         self._check(self._lib.cheetah_ctx_set_reserved_cus(self._h, int(cus)))
 
+    def set_launch_rounds(self, rounds):
+        """Rounds of the resident grid one ladder / fixed-base launch covers (default 2; raise it when nothing else needs
+        CU slots between launches)."""
+        self._check(self._lib.cheetah_ctx_set_launch_rounds(self._h, int(rounds)))
+
     def set_reference_schedule(self, on):
         """Tests / tools: run multiply_double_with_basepoint_vartime's affine results by the reference's Straus NAF
         schedule instead of the composed one (same results)."""

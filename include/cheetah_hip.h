@@ -77,6 +77,11 @@ int32_t cheetah_ctx_synchronize(cheetah_ctx *ctx);
  * default) sizes those launches smaller, so that such a kernel can always be placed.  No counterpart in the
  * reference (it has neither streams nor collectives); used by the multi-GPU path. */
 int32_t cheetah_ctx_set_reserved_cus(cheetah_ctx *ctx, int cus);
+/* A ladder or fixed-base call is issued as launches of at most `rounds` rounds of the resident grid (default 2: about
+ * 2^19 scalar multiplications, 17 ms), so that a kernel on another stream waits for a launch boundary no longer than
+ * that.  A caller with nothing else to place on the device may raise it (1 .. 256; 8 and more measure + 1 %).  No
+ * counterpart in the reference. */
+int32_t cheetah_ctx_set_launch_rounds(cheetah_ctx *ctx, int rounds);
 const char *cheetah_last_error(const cheetah_ctx *ctx); /* ctx may be NULL: last create error */
 const char *cheetah_version(void);
 

@@ -570,6 +570,34 @@ def test_reserved_cus_same_results(eng, ora):
     assert eng.multiply_units_per_launch(1 << 26) == full
 
 
+def test_launch_rounds_same_results(eng):
+    """cheetah_ctx_set_launch_rounds only changes how many rounds of the resident grid one launch covers: same results
+    over a batch that spans several launches at one round each; out-of-range values are rejected."""
+    from cheetah_amd import AFFINE, CheetahError
+    n = (1 << 19) + 777
+    sc = eng.synth_scalars(31, n)
+    pts, _ = eng.mul_by_generator_batch(sc, AFFINE)
+    k = eng.synth_scalars(32, n)
+    two = eng.multiply_units_per_launch(1 << 26)
+    a0, i0 = eng.multiply_batch(pts, k, AFFINE, AFFINE)
+    try:
+        eng.set_launch_rounds(1)
+        assert eng.multiply_units_per_launch(1 << 26) * 2 == two
+        a1, i1 = eng.multiply_batch(pts, k, AFFINE, AFFINE)
+        eng.set_launch_rounds(16)
+        assert eng.multiply_units_per_launch(1 << 26) == two * 8
+        a2, i2 = eng.multiply_batch(pts, k, AFFINE, AFFINE)
+        g2, _ = eng.mul_by_generator_batch(sc, AFFINE)
+        for bad in (0, 257, -1):
+            with pytest.raises(CheetahError):
+                eng.set_launch_rounds(bad)
+    finally:
+        eng.set_launch_rounds(2)
+    assert (host(a0) == host(a1)).all() and (host(a0) == host(a2)).all() and (host(i0) == host(i1)).all() and (host(i0) == host(i2)).all()
+    assert (host(g2) == host(pts)).all()
+    assert eng.multiply_units_per_launch(1 << 26) == two
+
+
 def test_torsion_and_cofactor_kats(eng, kats):
     """q * G = O through the full vartime ladder (is_torsion_free, src/curve/projective.rs:885-893, :1462);
     the reference's non-subgroup point is not killed by q but its cofactor multiple is (:1427-1433)."""
