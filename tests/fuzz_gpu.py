@@ -101,7 +101,7 @@ while time.time() < t_end:
         print("... %d runs, %d findings" % (runs, bad), flush=True)
         t_note = time.time() + 30
     n = int(rng.integers(1, max_n))
-    case = int(rng.integers(0, 12))
+    case = int(rng.integers(0, 17))
     in_form, out_form = pick_forms()
     aff = affine_points(n)
     pts = to_form(aff, in_form)
@@ -188,6 +188,71 @@ while time.time() < t_end:
             d = (eng.from_compressed_batch if comp else eng.from_uncompressed_batch)(D(bad_rec), chk)
             want = (enc,) + tuple(w)
             got = (e,) + tuple(d)
+        elif case == 12:
+            a = synth.fp6_elements(int(rng.integers(1, 1 << 30)), n).reshape(n, 6).copy()
+            b = synth.fp6_elements(int(rng.integers(1, 1 << 30)), n).reshape(n, 6).copy()
+            edge = np.array([0, 1, P - 1, P, 2**64 - 1, 2**32, 2**32 - 1, P + 1], np.uint64)
+            for _ in range(int(rng.integers(0, 8))):
+                (a if rng.random() < 0.5 else b)[int(rng.integers(0, n)), int(rng.integers(0, 6))] = edge[int(rng.integers(0, len(edge)))]
+            if rng.random() < 0.3:
+                a[int(rng.integers(0, n))] = 0                      # a zero: invert -> none
+            name = "fp6 mul / square / invert"
+            wi = ora.fp6_invert_batch(a)
+            gi = eng.fp6_invert_batch(D(a))
+            want = (ora.fp6_mul_batch(a, b).reshape(n, 6), ora.fp6_square_batch(a).reshape(n, 6), wi[0].reshape(n, 6), wi[1])
+            got = (eng.fp6_mul_batch(D(a), D(b)), eng.fp6_square_batch(D(a)), gi[0], gi[1])
+        elif case == 13:
+            m_ = min(n, 400)
+            a = rng.integers(0, 2**64, m_, dtype=np.uint64)
+            b = rng.integers(0, 2**64, m_, dtype=np.uint64)
+            edge = [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1]
+            for _ in range(int(rng.integers(0, 8))):
+                (a if rng.random() < 0.5 else b)[int(rng.integers(0, m_))] = edge[int(rng.integers(0, len(edge)))]
+            op = ["add", "sub", "neg", "double", "triple", "mul", "square", "mul_by_u32", "invert", "canonical"][int(rng.integers(0, 10))]
+            sc = int(rng.integers(0, 2**32))
+            ai, bi = [int(v) for v in a], [int(v) for v in b]
+            f = {"add": lambda x, y: x + y, "sub": lambda x, y: x - y, "neg": lambda x, y: -x, "double": lambda x, y: 2 * x,
+                 "triple": lambda x, y: 3 * x, "mul": lambda x, y: x * y, "square": lambda x, y: x * x,
+                 "mul_by_u32": lambda x, y: x * sc, "invert": lambda x, y: pow(x, P - 2, P), "canonical": lambda x, y: x}[op]
+            name = "fp_op %s" % op
+            w = np.array([f(x, y) % P for x, y in zip(ai, bi)], np.uint64)
+            g = eng.fp_op_batch(op, D(a), D(b) if op in ("add", "sub", "mul") else None, sc)
+            if op == "invert":
+                want = (w, np.array([1 if x % P else 0 for x in ai], np.uint8))
+                got = g
+            else:
+                want, got = (w,), (g,)
+        elif case == 14:
+            p = pts.copy()
+            for _ in range(int(rng.integers(0, 6))):
+                p[int(rng.integers(0, n)), int(rng.integers(0, p.shape[1]))] ^= np.uint64(1 << int(rng.integers(0, 63)))
+            name = "is_on_curve %d" % in_form
+            want = (ora.is_on_curve_batch(p, in_form),)
+            got = (eng.is_on_curve_batch(D(p), in_form),)
+        elif case == 15:
+            bf = AFFINE if in_form == JACOBIAN else in_form
+            base = to_form(affine_points(1), bf)
+            k = scalars(n)
+            k[:, 31] &= 0x7F
+            of = [AFFINE, PROJECTIVE][int(rng.integers(0, 2))]
+            name = "BasePointTable::create(P).multiply %d->%d" % (bf, of)
+            tab = ora.basepoint_table_create(base[0], bf)
+            t = eng.basepoint_table(base, bf)
+            try:
+                want = (tab[0],) + tuple(ora.basepoint_table_multiply_batch(tab, k, of))
+                got = (t.read(),) + tuple(H(x) for x in t.multiply_batch(D(k), of))
+                got = tuple(np.asarray(x) for x in got)
+                H = lambda a: a
+            finally:
+                t.close()
+        elif case == 16:
+            form = PROJECTIVE if in_form == AFFINE else in_form
+            p = to_form(aff, form)
+            qa = affine_points(n)
+            kk = int(rng.integers(1, 5))
+            name = "unchecked double_multi(%d) / add_mixed %d" % (kk, form)
+            want = (ora.double_multi_unchecked_batch(p, form, kk), ora.add_mixed_unchecked_batch(p, form, qa))
+            got = (eng.double_multi_unchecked_batch(D(p), kk, form), eng.add_mixed_unchecked_batch(D(p), D(qa), form))
         else:
             k = scalars(n)
             of = [AFFINE, PROJECTIVE, JACOBIAN][int(rng.integers(0, 3))]
