@@ -210,6 +210,17 @@ def test_host_pipeline_many_chunks_equals_device_path(eng):
     assert (got2 == got[:1000]).all()
     nxy, ninf = eng.batch_normalize(host(eng.multiply_batch(pts_d[:5000], dev(k[:5000]), AFFINE, JACOBIAN)[0]), JACOBIAN)
     assert (nxy == got[:5000]).all()
+    # fixed base from host arrays: the kernels store into the page-locked staging themselves (no device-to-host copy)
+    g = 5 * (1 << 18) + 333
+    r = host(eng.synth_scalars(35, g))
+    for form in (AFFINE, PROJECTIVE, JACOBIAN):
+        got, ginf = eng.mul_by_generator_batch(r, form)
+        want, winf = eng.mul_by_generator_batch(dev(r), form)
+        assert (got == host(want)).all() and (ginf == host(winf)).all(), form
+    got2, _ = eng.mul_by_generator_batch(r[:70000], AFFINE)    # one chunk, page-locked; then a small call with direct copies
+    got3, _ = eng.mul_by_generator_batch(r[:100], AFFINE)
+    want, _ = eng.mul_by_generator_batch(dev(r[:70000]), AFFINE)
+    assert (got2 == host(want)).all() and (got3 == host(want)[:100]).all()
 
 
 # ------------------------------------------------------------ BasePointTable -----
