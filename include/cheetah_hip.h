@@ -141,7 +141,9 @@ int32_t cheetah_batch_normalize_projective_dev(cheetah_ctx *ctx, const uint64_t 
 int32_t cheetah_batch_normalize_jacobian_dev(cheetah_ctx *ctx, const uint64_t *xyz, uint64_t *xy, uint8_t *inf, size_t n);
 
 /* ---- fixed base, constant time --------------------------------------------
- * out[i] = scalars[i] * G.
+ * out[i] = scalars[i] * G.  Constant time on the device means: no branch and no memory address depends on a scalar;
+ * a table lookup goes over every entry of the window's table at addresses all lanes share (the reference's scan,
+ * src/lookup.rs:81-102), and only which lanes are enabled for which entry's read depends on the digit.
  * out_form = CHEETAH_AFFINE    : the affine point of &BASEPOINT_TABLE * &Scalar = BasePointTable::multiply
  *                                (src/lookup.rs:189-206, src/constants.rs:92-98); out = 12 limbs per
  *                                point, inf[i] set.  An affine point does not depend on the schedule
