@@ -1,7 +1,8 @@
 """Seeded, counter-based synthetic inputs (host side, numpy).
 
-The same generator is implemented on the device (csrc/synth_kernels.hip) so that
-large benchmark inputs never cross PCIe; tests check the two agree.
+The same generator is implemented on the device (k_synth_fp6 / k_synth_scalars,
+csrc/kernels.hip.h) so that large benchmark inputs never cross PCIe; tests check
+the two agree.
 
     splitmix64(seed, i) = mix(seed + (i + 1) * 0x9E3779B97F4A7C15)
 
@@ -38,7 +39,32 @@ def fp6_elements(seed, n, start=0):
 
 
 def scalars(seed, n, start=0):
-    """n canonical scalars as (n, 32) uint8 little-endian bytes."""
+    """n canonical scalars as (n, 32) uint8 little-endian bytes.  Vectorised: 2^256 / q < 3, so
+    three conditional subtractions of q (limb-wise, with borrow) reduce any draw."""
+    idx = np.arange(4 * start, 4 * (start + n), dtype=np.uint64)
+    v = splitmix64(seed, idx).reshape(n, 4).copy()
+    ql = [np.uint64(x) for x in Q_LIMBS]
+    one, zero = np.uint64(1), np.uint64(0)
+    with np.errstate(over="ignore"):
+        for _ in range(3):
+            ge = np.ones(n, dtype=bool)       # v >= q, decided from the top limb down
+            decided = np.zeros(n, dtype=bool)
+            for j in (3, 2, 1, 0):
+                gt, lt = v[:, j] > ql[j], v[:, j] < ql[j]
+                ge = np.where(~decided & lt, False, ge)
+                decided |= gt | lt
+            borrow = np.zeros(n, dtype=np.uint64)
+            for j in range(4):
+                sub = ql[j] + borrow              # wraps only when q_j = 2^64 - 1 and borrow = 1 (never: no such limb)
+                d = v[:, j] - sub
+                nb = np.where(v[:, j] < sub, one, zero)
+                v[:, j] = np.where(ge, d, v[:, j])
+                borrow = nb
+    return np.ascontiguousarray(v).view(np.uint8).reshape(n, 32)
+
+
+def scalars_reference(seed, n, start=0):
+    """The same scalars by Python integers (the definition; slow).  tests/ compare the two."""
     idx = np.arange(4 * start, 4 * (start + n), dtype=np.uint64)
     limbs = splitmix64(seed, idx).reshape(n, 4)
     out = np.empty((n, 4), dtype=np.uint64)
