@@ -159,11 +159,41 @@ template <> struct Ladder<MJac> {
     static CH_DEV MJac add_inl(const MJac& p, const Affine& q) { return mjac_add_mixed_impl<true, true, true>(p, q); }
 };
 
+CH_DEV Fp6 curve_b() {  // B = u + 395, src/curve/mod.rs:42-49
+    Fp6 b = fp6_zero();
+    b.c[0] = 395;
+    b.c[1] = 1;
+    return b;
+}
+
 // (0, 1) is the affine encoding of the identity (src/curve/affine.rs:224-230); it is not a point of the curve
 // (1 != B), so the encoding is unambiguous.
 CH_DEV bool affine_is_identity_encoding(const Fp6& x, const Fp6& y) {
     return fp6_is_zero(x) && fp_canonical(y.c[0]) == 1 && fp_is_zero(y.c[1]) && fp_is_zero(y.c[2]) && fp_is_zero(y.c[3]) &&
            fp_is_zero(y.c[4]) && fp_is_zero(y.c[5]);
+}
+
+// is_on_curve of the three point types as device predicates (src/curve/affine.rs:364-368, projective.rs:940-946,
+// jacobian.rs:930-938); the identity (its (0, 1) encoding, z == 0) counts as on the curve, as there.
+CH_DEV bool affine_on_curve(const Fp6& x, const Fp6& y) {
+    const Fp6 lhs = fp6_sub(fp6_square(y), fp6_mul(x, fp6_add(fp6_square(x), fp6_one())));  // y^2 - x (x^2 + 1) == B
+    return fp6_eq(lhs, curve_b());
+}
+template <int FORM>
+CH_DEV bool point_on_curve(const u64* pts, size_t i) {
+    if (FORM == 0) {
+        const Affine p = load_affine(pts + 12 * i);
+        return affine_on_curve(p.x, p.y) || affine_is_identity_encoding(p.x, p.y);
+    }
+    const Proj p = load_proj(pts + 18 * i);
+    const Fp6 x3 = fp6_mul(fp6_square(p.x), p.x), z2 = fp6_square(p.z);
+    if (FORM == 1) {
+        const Fp6 rhs = fp6_add(fp6_add(x3, fp6_mul(p.x, z2)), fp6_mul(fp6_mul(z2, p.z), curve_b()));
+        return fp6_eq(fp6_mul(fp6_square(p.y), p.z), rhs) || fp6_is_zero(p.z);
+    }
+    const Fp6 z4 = fp6_square(z2);
+    const Fp6 rhs = fp6_add(fp6_add(x3, fp6_mul(p.x, z4)), fp6_mul(fp6_mul(z2, z4), curve_b()));
+    return fp6_eq(fp6_square(p.y), rhs) || fp6_is_zero(p.z);
 }
 
 // The point whose multiples fill the window table, as a projective point:
@@ -943,7 +973,12 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
         pa.y = p.y;
         pa.inf = fp6_is_zero(p.z);
     }
-    const bool ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t);
+    // The chord / tangent steps know nothing of B: for a point that is NOT on the curve they would fill the table with
+    // its multiples on another curve, while the reference's complete additions (which use 3B) produce other values --
+    // and those are what LookupTable::from returns (such inputs exist: from_uncompressed_unchecked, unchecked decoding).
+    // An off-curve lane therefore sends its wave to the reference's construction as well (2 S + 1 M per lane).
+    bool ok = pa.inf || affine_on_curve(pa.x, pa.y);
+    ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t) && ok;
     if (__any(!ok)) {
         Proj p = load_input_point<IN_FORM>(pts, i);
         if (IN_FORM == 1 && NAF_IDENTITY && fp6_is_zero(p.z)) p = proj_identity();
@@ -1029,7 +1064,9 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
         // canonical scalars (< 2^255) only ever select entries 1..8; a wave builds
         // all 16 entries of LookupTable<16> only if one of its lanes needs them
         const bool wide = (k[3] >> 60) > 7;
-        if (DIRECT && __any((int)(k[3] >> 63))) continue;  // this wave belongs to the NAF kernel
+        // DIRECT: a wave that holds a scalar with bit 255 set, or a point that is not on the curve (for which the two
+        // ladders, fed by different tables, disagree), belongs to the NAF kernel (ONLY_WIDE, the same predicate)
+        if (DIRECT && __any((int)(k[3] >> 63) | (int)!point_on_curve<IN_FORM>(pts, ii))) continue;
         const int n_entries = __any(wide) ? 16 : 8;
         const u32 ident = build_lookup_table<IN_FORM, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
         const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
@@ -1063,11 +1100,13 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
         const size_t ii = active ? i : n - 1;
         u64 k[4];
         load_scalar(scalars, uniform_scalar ? 0 : ii, k);  // uniform: is_torsion_free / clear_cofactor (one fixed scalar)
-        if (ONLY_WIDE && !__syncthreads_or((int)(k[3] >> 63))) continue;  // no such scalar in this workgroup
+        int redo = 0;  // ONLY_WIDE: the waves k_multiply_ct<..., DIRECT> left out (its predicate)
+        if (ONLY_WIDE) redo = (int)(k[3] >> 63) | (int)!point_on_curve<IN_FORM>(pts, ii);
+        if (ONLY_WIDE && !__syncthreads_or(redo)) continue;  // no such wave in this workgroup
         __syncthreads();
         recode_wnaf5_packed(k, s_naf, t);
         __syncthreads();
-        if (ONLY_WIDE && !__any((int)(k[3] >> 63))) continue;
+        if (ONLY_WIDE && !__any(redo)) continue;
         const Proj p = load_input_point<IN_FORM>(pts, ii);
         const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
         ACC acc = Ladder<ACC>::from_affine(shift);
@@ -1151,6 +1190,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
             load_scalar(scalars, gg * m + j, k);
             recode_radix16(k, s_dig + (size_t)j * 256 * BLOCK, t);
             wide = wide || (k[3] >> 60) > 7;
+            if (DIRECT) wide = wide || !point_on_curve<IN_FORM>(pts, gg * m + j);  // off the curve: the ladders disagree
         }
         if (DIRECT && __any(wide)) continue;  // top nibble > 7 <=> bit 255 set: this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
@@ -1197,6 +1237,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
         if (ONLY_WIDE) {
             int wide = 0;
             for (int j = 0; j < ns; j++) wide |= (int)(scalars[(gg * ns + j) * 32 + 31] >> 7);
+            for (int j = 0; j < m; j++) wide |= (int)!point_on_curve<IN_FORM>(pts, gg * m + j);
             if (!__any(wide)) continue;
         }
         for (int j = 0; j < ns; j++) {
@@ -1504,34 +1545,10 @@ __global__ void __launch_bounds__(BLOCK) k_zero_rejected(u64* __restrict__ xy, u
 // is_on_curve: AffinePoint (FORM 0, src/curve/affine.rs:364-368: y^2 - x (x^2 + 1) == B, or the identity),
 // ProjectivePoint (FORM 1, src/curve/projective.rs:940-946: Y^2 Z == X^3 + X Z^2 + B Z^3, or Z == 0),
 // JacobianPoint (FORM 2, src/curve/jacobian.rs:930-938: Y^2 == X^3 + X Z^4 + B Z^6, or Z == 0).
-CH_DEV Fp6 curve_b() {  // B = u + 395, src/curve/mod.rs:42-49
-    Fp6 b = fp6_zero();
-    b.c[0] = 395;
-    b.c[1] = 1;
-    return b;
-}
 template <int FORM>
 __global__ void __launch_bounds__(BLOCK) k_is_on_curve(const u64* __restrict__ pts, u8* __restrict__ flags, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        bool ok;
-        if (FORM == 0) {
-            const Affine p = load_affine(pts + 12 * i);
-            const Fp6 lhs = fp6_sub(fp6_square(p.y), fp6_mul(p.x, fp6_add(fp6_square(p.x), fp6_one())));
-            ok = fp6_eq(lhs, curve_b()) || affine_is_identity_encoding(p.x, p.y);
-        } else {
-            const Proj p = load_proj(pts + 18 * i);
-            const Fp6 x3 = fp6_mul(fp6_square(p.x), p.x), z2 = fp6_square(p.z);
-            if (FORM == 1) {
-                const Fp6 rhs = fp6_add(fp6_add(x3, fp6_mul(p.x, z2)), fp6_mul(fp6_mul(z2, p.z), curve_b()));
-                ok = fp6_eq(fp6_mul(fp6_square(p.y), p.z), rhs) || fp6_is_zero(p.z);
-            } else {
-                const Fp6 z4 = fp6_square(z2);
-                const Fp6 rhs = fp6_add(fp6_add(x3, fp6_mul(p.x, z4)), fp6_mul(fp6_mul(z2, z4), curve_b()));
-                ok = fp6_eq(fp6_square(p.y), rhs) || fp6_is_zero(p.z);
-            }
-        }
-        flags[i] = ok ? 1 : 0;
-    }
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+        flags[i] = point_on_curve<FORM>(pts, i) ? 1 : 0;
 }
 
 // Complete group law over a batch: out[i] = lhs[i] + rhs[i] (LHS_FORM 1: ProjectivePoint::add / add_mixed,

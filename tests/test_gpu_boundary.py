@@ -395,3 +395,48 @@ def test_multiply_low_order_points_fall_back_to_the_complete_formulas(eng, ora, 
             want, winf = ora.multiply_batch(arr, form, k, out_form)
             got, ginf = eng.multiply_batch(dev(arr), dev(k), form, out_form)
             assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, out_form)
+
+
+# ------------------------------------------- off-curve inputs (window-table fallback) -----
+
+def test_off_curve_inputs_match_the_reference_through_every_ladder(eng, ora):
+    """Points that are NOT on the curve reach the ladders through from_uncompressed_unchecked / unchecked decoding.
+    The reference fills LookupTable<N> with its complete additions (which use 3B), so what it returns for such a
+    point is a definite value -- not a multiple on any curve.  The affine chord / tangent table construction would give
+    other values, so an off-curve lane sends its wave to the reference's construction (build_lookup_table).  Perturbed
+    affine, projective and Jacobian inputs (first wave, a later wave) through multiply, multiply_vartime,
+    multiply_many(_vartime) and multiply_double_with_basepoint_vartime against the oracle, all result forms."""
+    n = 330
+    pts = points(eng, 71, n)
+    for i in (1, 64, 65, 200, 329):
+        pts[i, 0] ^= np.uint64(1 + i)                 # x off the curve
+    pts[2, 7] = (int(pts[2, 7]) + 5) % P              # y off the curve
+    pts[130] = np.array(list(range(1, 13)), np.uint64)
+    assert ora.is_on_curve_batch(pts, 0)[[1, 2, 64, 65, 130, 200, 329]].sum() == 0
+    k = synth.scalars(72, n).copy()
+    k[64] = 0xFF                                      # a 16-entry table next to an off-curve lane
+    lam = synth.fp6_elements(73, n)
+    l2 = eng.fp6_square_batch(lam)
+    l3 = eng.fp6_mul_batch(l2, lam)
+    jac = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), l2), eng.fp6_mul_batch(pts[:, 6:].copy(), l3), lam], axis=1)
+    prj = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), lam), eng.fp6_mul_batch(pts[:, 6:].copy(), lam), lam], axis=1)
+    for i in range(3, n, 97):
+        jac[i, 12:] = 0
+        prj[i, 12:] = 0
+    for arr, form in ((pts, AFFINE), (jac, JACOBIAN), (prj, PROJECTIVE)):
+        for out_form in sorted({AFFINE, form if form != AFFINE else JACOBIAN, PROJECTIVE if form == AFFINE else form}):
+            for vt in (False, True):
+                want, winf = ora.multiply_batch(arr, form, k, out_form, vartime=vt)
+                f = eng.multiply_vartime_batch if vt else eng.multiply_batch
+                got, ginf = f(dev(arr), dev(k), form, out_form)
+                assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, out_form, vt)
+        m = 2
+        for vt in (False, True):
+            want, winf = ora.multiply_many_batch(arr, form, k, m, 0, vartime=vt)
+            f = eng.multiply_many_vartime_batch if vt else eng.multiply_many_batch
+            got, ginf = f(dev(arr), dev(k), m, form, AFFINE)
+            assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, "many", vt)
+        kk = np.ascontiguousarray(np.stack([k, synth.scalars(74, n)], axis=1).reshape(2 * n, 32))
+        want, winf = ora.multiply_many_batch(arr, form, kk, 1, 0, vartime=True, with_basepoint=True)
+        got, ginf = eng.multiply_double_with_basepoint_vartime_batch(dev(arr), dev(kk), form, AFFINE)
+        assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, "with_basepoint")
