@@ -190,10 +190,16 @@ def rehearse(args, world, rank):
         dist.barrier()
     dt = time.perf_counter() - t0
     ones = torch.ones(1, dtype=torch.int64)
+    # the same pass without the gather (report both)
+    t1 = time.perf_counter()
+    sharded_apply(compute, n, 12, rank, world, chunks, "cpu", gather=False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
+        dist.barrier()
+    dt_ng = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt, dt_ng], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_ng = float(t[0].item()), float(t[1].item())
         dist.all_reduce(ones)
     want = torch.arange(n * 12, dtype=torch.int64).reshape(n, 12)
     ok = bool(torch.equal(xy, want)) and int(inf.sum()) == len(range(0, n, 5))
@@ -204,6 +210,7 @@ def rehearse(args, world, rank):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "REHEARSAL on CPU over gloo: stand-in for the arithmetic, not a measurement",
             "rehearsal": True, "ranks_seen": int(ones.item()), "gathered_ok": ok,
+            "compute_ms": dt_ng * 1e3, "no_gather_value": n / dt_ng, "gather_ms_exposed": dt / args.steps * 1e3 - dt_ng * 1e3,
             "checksum": "%016x" % (int(xy.sum().item()) & 0xFFFFFFFFFFFFFFFF),
             "config": {"workload": "launcher / sharding / all-gather rehearsal", "n": n, "per_gpu": n // world,
                        "allgather_chunks": chunks, "parallelism": "shard%d" % world}}), flush=True)
@@ -381,15 +388,14 @@ def main():
 
     # ---- what the gather costs: the same pass without it (this rank's blocks only) --------
     ones = torch.ones(1, dtype=torch.int64, device=device)
-    compute_ms = None
     if dist_on:
         dist.all_reduce(ones)                     # ranks_seen: a sum of ones over RCCL
-        barrier()
-        t0 = time.perf_counter()
-        o = step(gather=False)
-        barrier()
-        compute_ms = max_over_ranks(time.perf_counter() - t0) * 1e3
-        del o
+    barrier()
+    t0 = time.perf_counter()
+    o = step(gather=False)                        # every N, N = 1 included (report both)
+    barrier()
+    compute_ms = max_over_ranks(time.perf_counter() - t0) * 1e3
+    del o
 
     # ---- roofline of the dominant kernel (k_multiply_ct), measured live ---------
     ms_launch, units_per_launch, n_launches = timed_kernel_pass()   # averages over the pass's kernel launches
@@ -448,9 +454,10 @@ def main():
         }
         if args.rccl_at_one:
             line["rccl_at_one"] = True
-        if compute_ms is not None:
-            line["compute_ms"] = compute_ms
-            line["gather_ms_exposed"] = dt / args.steps * 1e3 - compute_ms
+        # the no-gather mode (results stay sharded on the ranks that computed them): one pass, max over ranks
+        line["compute_ms"] = compute_ms
+        line["no_gather_value"] = n / (compute_ms * 1e-3)
+        line["gather_ms_exposed"] = dt / args.steps * 1e3 - compute_ms
         line.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

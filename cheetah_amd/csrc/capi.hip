@@ -647,7 +647,14 @@ static int32_t run_host(cheetah_ctx* ctx, const Op& op) {
         cheetah_ctx* c = i == 0 ? ctx : ctx->subs[i - 1];
         size_t off, cnt;
         shard_range(op.n, nsh, i, &off, &cnt);
-        th.emplace_back([&rcs, &op, c, off, cnt, i]() { rcs[i] = host_pipeline(c, op, off, cnt); });
+        // a thread that cannot be started (std::system_error) must not unwind through the extern "C" caller with
+        // earlier threads still joinable: that shard runs on the calling thread instead
+        try {
+            th.reserve(nsh);
+            th.emplace_back([&rcs, &op, c, off, cnt, i]() { rcs[i] = host_pipeline(c, op, off, cnt); });
+        } catch (...) {
+            rcs[i] = host_pipeline(c, op, off, cnt);
+        }
     }
     for (auto& t : th) t.join();
     (void)hipSetDevice(ctx->device);

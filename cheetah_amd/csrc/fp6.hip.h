@@ -85,11 +85,13 @@ CH_DEV Fp6 fp6_mul_by_fp(const Fp6& a, u64 k) {  // src/fp6.rs:448-464
     for (int i = 0; i < 6; i++) r.c[i] = fp_mul(a.c[i], k);
     return r;
 }
+// Branch-free on purpose (one OR over the canonical limbs): written as a chain of `&&` the compiler turned it into a
+// chain of divergent branches, i.e. control flow on the operand (tools/check_ct_isa.py).
 CH_DEV bool fp6_is_zero(const Fp6& a) {  // src/fp6.rs:362-369
-    bool z = true;
+    u64 acc = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) z = z && fp_is_zero(a.c[i]);
-    return z;
+    for (int i = 0; i < 6; i++) acc |= fp_canonical(a.c[i]);
+    return acc == 0;
 }
 // subtle's conditional_select(a, b, choice) = choice ? b : a   (src/fp6.rs:247-258)
 CH_DEV Fp6 fp6_select(const Fp6& a, const Fp6& b, bool choice) {
@@ -343,10 +345,10 @@ CH_DEV Fp6 fp6_mul_by_high_fp3(const Fp6& s, const Fp3& f) {
     return r;
 }
 CH_DEV bool fp6_eq(const Fp6& a, const Fp6& b) {
-    bool e = true;
+    u64 acc = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) e = e && fp_canonical(a.c[i]) == fp_canonical(b.c[i]);
-    return e;
+    for (int i = 0; i < 6; i++) acc |= fp_canonical(a.c[i]) ^ fp_canonical(b.c[i]);
+    return acc == 0;
 }
 // Fp6::sqrt, Algorithm 10 of eprint 2012/685 as in src/fp6.rs:922-964.
 CH_DEV Fp6 fp6_sqrt(const Fp6& self, bool* is_some) {

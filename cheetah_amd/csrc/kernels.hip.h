@@ -168,9 +168,13 @@ CH_DEV Fp6 curve_b() {  // B = u + 395, src/curve/mod.rs:42-49
 
 // (0, 1) is the affine encoding of the identity (src/curve/affine.rs:224-230); it is not a point of the curve
 // (1 != B), so the encoding is unambiguous.
-CH_DEV bool affine_is_identity_encoding(const Fp6& x, const Fp6& y) {
-    return fp6_is_zero(x) && fp_canonical(y.c[0]) == 1 && fp_is_zero(y.c[1]) && fp_is_zero(y.c[2]) && fp_is_zero(y.c[3]) &&
-           fp_is_zero(y.c[4]) && fp_is_zero(y.c[5]);
+CH_DEV bool affine_is_identity_encoding(const Fp6& x, const Fp6& y) {  // branch-free, like fp6_is_zero
+    u64 acc = fp_canonical(y.c[0]) ^ 1ull;
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc |= fp_canonical(x.c[i]);
+#pragma unroll
+    for (int i = 1; i < 6; i++) acc |= fp_canonical(y.c[i]);
+    return acc == 0;
 }
 
 // is_on_curve of the three point types as device predicates (src/curve/affine.rs:364-368, projective.rs:940-946,
@@ -654,7 +658,7 @@ CH_DEV Affine lds_lookup_seq(const u64* sub, int d, std::integer_sequence<int, J
         t.y.c[2 * l + 1] = q[3 + l].y;
     }
     t.inf = dabs == 0;
-    if (GENERIC) t.inf = t.inf || affine_is_identity_encoding(t.x, t.y);
+    if (GENERIC) t.inf = t.inf | affine_is_identity_encoding(t.x, t.y);  // `|`: no short-circuit branch on the digit
     return affine_cond_neg(t, neg);
 }
 // entry |d| (1-based) of N affine entries of 96 bytes at `sub` (LDS, 16-byte aligned), negated for d < 0; (0, 1, inf) for d = 0

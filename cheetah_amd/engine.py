@@ -310,8 +310,14 @@ class Engine:
         """multiply_batch on device tensors through the entry point that allocates nothing
         (cheetah_multiply_batch_dev_noalloc): `out` and `inf` must be given."""
         w, wi = self._out_width(out_form), self._out_width(in_form)
+        if out is None or inf is None:
+            raise ValueError("multiply_batch_noalloc allocates nothing: pass `out` and `inf` (device tensors)")
         p, s = self._dev(pts, 8, wi), self._dev(scalars, 1, 32)
         out = self._dev(out, 8, w)
+        if not _is_torch(inf) or inf.dtype != torch.uint8 or not inf.is_contiguous() or inf.numel() != s.shape[0]:
+            raise ValueError("inf must be a contiguous uint8 device tensor with one byte per element")
+        if out.shape[0] != s.shape[0] or p.shape[0] != s.shape[0]:
+            raise ValueError("pts, scalars and out must hold the same number of elements")
         self._use_torch_stream()
         self._check(self._lib.cheetah_multiply_batch_dev_noalloc(self._h, p.data_ptr(), in_form, s.data_ptr(), out.data_ptr(),
                                                                  inf.data_ptr(), s.shape[0], out_form))

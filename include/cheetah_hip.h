@@ -208,7 +208,16 @@ int32_t cheetah_basepoint_table_read(cheetah_ctx *ctx, const cheetah_basepoint_t
  *           CHEETAH_JACOBIAN (18 limbs).
  * out_form: AFFINE = 12 limbs + inf; PROJECTIVE / JACOBIAN = the reference's own (X, Y, Z) of that
  *           method, 18 canonical limbs, inf[i] = (Z == 0), inf may be NULL.
- * Any 32 bytes are accepted as a scalar, as in the reference. */
+ * Any 32 bytes are accepted as a scalar, as in the reference.
+ * Constant time, for cheetah_multiply_batch, means: no branch and no memory address in the window loops depends on a
+ * digit of a canonical scalar (re-checked on the ISA of every build, tools/check_ct_isa.py).  It does NOT mean
+ * independence of the POINTS: a wave that holds the identity, a point of order <= 16 or a point that is not on the
+ * curve rebuilds its window tables with the reference's complete additions (src/lookup.rs:25-37) instead of the
+ * shared-inversion affine steps, and a wave that holds a scalar with the top nibble > 7 (no canonical scalar) builds
+ * 16 table entries instead of 8.  The reference's LookupTable::from has neither branch.
+ * Points are not required to be on the curve (the reference does not check either): such inputs return what the
+ * reference's formulas return for them, by the reference's own table construction and, for the vartime entry
+ * points, its own NAF schedule (tests/test_gpu_boundary.py). */
 int32_t cheetah_multiply_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
                                uint64_t *out, uint8_t *inf, size_t n, int out_form);
 int32_t cheetah_multiply_vartime_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,

@@ -26,9 +26,12 @@ def test_launcher_starts_two_ranks_and_forwards_one_line():
     assert line["rehearsal"] is True and line["gathered_ok"] is True
     assert line["config"]["per_gpu"] == 2048 and line["config"]["allgather_chunks"] == 8
     assert line["scaling"] == "strong" and line["unit"] == "scalar_mults/s" and line["value"] > 0
+    # both modes are reported for every N: with the all-gather (value) and without it (no_gather_value)
+    assert line["compute_ms"] > 0 and line["no_gather_value"] > 0 and "gather_ms_exposed" in line
     # the gathered array is the same whatever the number of ranks
     one = json.loads(_run("--rehearse-cpu", "--log2n", "12", "--steps", "1", "--warmup", "0").stdout.strip())
     assert one["n_gpus"] == 1 and one["checksum"] == line["checksum"]
+    assert one["ranks_seen"] == 1 and one["compute_ms"] > 0 and one["no_gather_value"] > 0 and "gather_ms_exposed" in one
 
 
 def test_launcher_fails_clearly_without_enough_gpus():

@@ -22,9 +22,14 @@ def _run(lib, h, fn, pts, in_form, ks, out_form):
     out = torch.full((n, w), -1, dtype=torch.int64, device="cuda")
     inf = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]          # hipMemGetInfo: device memory free on this GPU
     rc = fn(h, pts.data_ptr(), in_form, ks.data_ptr(), out.data_ptr(), inf.data_ptr(), n, out_form)
     assert rc == 0, lib.cheetah_last_error(h)
     assert lib.cheetah_ctx_synchronize(h) == 0
+    if fn is lib.cheetah_multiply_batch_dev_noalloc:
+        # the property the entry point exists for: the call took no device memory (nothing else runs in this process
+        # between the two readings; torch allocates nothing here, the outputs exist already)
+        assert torch.cuda.mem_get_info()[0] == free_before, "cheetah_multiply_batch_dev_noalloc changed the free device memory"
     return out.cpu().numpy(), inf.cpu().numpy()
 
 
