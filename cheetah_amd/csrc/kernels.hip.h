@@ -27,7 +27,12 @@ constexpr int BLOCK = 256;
 #define CH_VT_PARK 48  // NAF kernels: the wave adds once this many of its 64 lanes are parked at a non-zero digit
 #endif
 #ifndef CH_MANY_WAVES
-#define CH_MANY_WAVES 2
+// Multi-scalar kernels.  Measured in round 3 (tools/lab/many_lab.py, 2^19 groups, m = 2 constant time / indexed): 2 waves
+// per SIMD (226 VGPRs, no spill) 20.4 / 21.6 M groups/s; 3 waves (168 VGPRs, 68 spilled) 23.4 / 24.5; 4 waves (128 VGPRs,
+// 124 spilled) 22.4 / 23.6; m = 4: 12.8 / 14.3 / 13.8 (ct).  Keeping the radix-16 digits in LDS, two per byte, instead of
+// one byte per digit in global scratch changes nothing at any occupancy (+- 0.2 %), and the window's additions through
+// calls instead of inlined are 1 - 3 % slower: what bounds these kernels is the number of resident waves.
+#define CH_MANY_WAVES 3
 #endif
 #ifndef CH_BN_WAVES
 #define CH_BN_WAVES 3
@@ -428,6 +433,9 @@ __global__ void __launch_bounds__(BLOCK) k_fp_op(int op, const u64* __restrict__
 #ifndef CH_BN_NREG
 #define CH_BN_NREG 1
 #endif
+#ifndef CH_BN_FASTPATH
+#define CH_BN_FASTPATH 1   // wave-uniform skip of the identity selects (round 3; A/B in tools/lab/bn_lab.py)
+#endif
 template <int JAC>
 __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u64* __restrict__ xyz, u64* __restrict__ xy,
                                                                      u8* __restrict__ inf, size_t n) {
@@ -455,7 +463,13 @@ __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u6
                 for (int l = 0; l < 6; l++) s_prefix[((j - 1 - NREG) * 6 + l) * BLOCK + t] = acc.c[l];
             }
             const Fp6 m = fp6_mul_inl(acc, z);
+#if CH_BN_FASTPATH
+            const bool zz = fp6_is_zero(z);
+            if (__any(zz)) acc = fp6_select(m, acc, zz);  // identities are rare: the selects run only in a wave that holds one
+            else acc = m;
+#else
             acc = fp6_select(m, acc, fp6_is_zero(z));
+#endif
         }
         bool some;
         acc = fp6_invert(acc, &some);
@@ -482,6 +496,9 @@ __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u6
                 nz = in ? load_fp6_vec(p + 12) : fp6_zero();
             }
             const bool skip = fp6_is_zero(z);
+#if CH_BN_FASTPATH
+            const bool any_skip = __any(skip);
+#endif
             Fp6 zi = acc;  // 1 / z_j
             if (j > 0) {
                 Fp6 pre = (NREG == 2 && j == 2) ? pre2 : pre1;
@@ -491,7 +508,12 @@ __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u6
                 }
                 zi = fp6_mul_inl(pre, acc);
                 const Fp6 m = fp6_mul_inl(acc, z);
+#if CH_BN_FASTPATH
+                if (any_skip) acc = fp6_select(m, acc, skip);
+                else acc = m;
+#else
                 acc = fp6_select(m, acc, skip);
+#endif
             }
             Affine o;
             if (JAC) {
@@ -503,7 +525,15 @@ __global__ void __launch_bounds__(BLOCK, CH_BN_WAVES) k_batch_normalize(const u6
                 o.y = fp6_mul_inl(y, zi);
             }
             o.inf = false;
+#if CH_BN_FASTPATH
+            if (any_skip) {
+                o.x = fp6_select(o.x, fp6_zero(), skip);
+                o.y = fp6_select(o.y, fp6_one(), skip);
+                o.inf = skip;
+            }
+#else
             if (skip) o = affine_identity();
+#endif
             if (e < n) {
                 store_fp6_vec_canonical(xy + 12 * e, o.x);
                 store_fp6_vec_canonical(xy + 12 * e + 6, o.y);

@@ -7,6 +7,8 @@ import torch
 from cheetah_amd import AFFINE, Engine
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 eng = Engine(0)
+if len(sys.argv) > 2:
+    eng.set_launch_rounds(int(sys.argv[2]))   # rounds of the resident grid per launch (library default 2)
 for m in (2, 4):
     g = 1 << lg
     n = g * m
