@@ -55,6 +55,9 @@ SIGNATURES = {
     "cheetah_ctx_set_launch_rounds": (C.c_int32, [_vp, _i]),
     "cheetah_last_error": (C.c_char_p, [_vp]),
     "cheetah_version": (C.c_char_p, []),
+    "cheetah_fp6_exp_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_fp6_exp_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
+    "cheetah_random_points_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _sz, _i]),
     "cheetah_fp6_mul_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_fp6_square_batch": (C.c_int32, [_vp, _vp, _vp, _sz]),
     "cheetah_fp6_invert_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),

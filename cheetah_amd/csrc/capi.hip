@@ -832,6 +832,32 @@ extern "C" int32_t cheetah_fp6_op_batch_dev(cheetah_ctx* ctx, int op, const uint
 extern "C" int32_t cheetah_fp6_op_batch(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t scalar, uint64_t* out, size_t n) {
     return fp6_op_op(ctx, true, op, a, b, scalar, out, n);
 }
+// Fp6::exp / exp_vartime (src/fp6.rs:1053-1086) over a batch: one 384-bit exponent (HOST pointer, 6 limbs) for all elements.
+static int32_t fp6_exp_op(cheetah_ctx* ctx, bool host, const u64* a, const u64* power6, u64* out, size_t n) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (!power6) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    u64 pw[6];
+    for (int i = 0; i < 6; i++) pw[i] = power6[i];
+    Op o;
+    o.n = n;
+    o.chunk = (size_t)1 << 18;
+    o.io = {in_(a, 48), out_(out, 48)};
+    o.launch = [pw](cheetah_ctx* c, void* const* d, size_t cnt) -> int32_t {
+        SET_DEVICE(c);
+        if (!aligned16(d[0]) || !aligned16(d[1])) return fail(c, CHEETAH_ERR_INVALID, "Fp6 device arrays must be 16-byte aligned");
+        hipLaunchKernelGGL(k_fp6_exp, dim3(ew_grid(c, cnt)), dim3(BLOCK), 0, c->stream, at<u64>(d, 0), pw[0], pw[1], pw[2], pw[3], pw[4], pw[5],
+                           at<u64>(d, 1), cnt);
+        HIP_TRY(c, hipGetLastError());
+        return CHEETAH_OK;
+    };
+    return run_op(ctx, host, o);
+}
+extern "C" int32_t cheetah_fp6_exp_batch(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* power6, uint64_t* out, size_t n) {
+    return fp6_exp_op(ctx, true, a, power6, out, n);
+}
+extern "C" int32_t cheetah_fp6_exp_batch_dev(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* power6, uint64_t* out, size_t n) {
+    return fp6_exp_op(ctx, false, a, power6, out, n);
+}
 extern "C" int32_t cheetah_fp6_mul_batch_dev(cheetah_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     return fp6_mul_op(ctx, false, a, b, out, n);
 }
@@ -1097,21 +1123,27 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
     // multiply_vartime with AFFINE results: the fixed-window ladder with indexed lookups (k_multiply_ct<..., DIRECT>)
     // for every wave whose scalars are all below 2^255, then the reference's NAF ladder for the remaining waves.
     const bool direct = VARTIME && out_form == CHEETAH_AFFINE;
+    // multiply_vartime with the reference's own representative (L2): the pooled NAF kernel, VtPool::SLOTS x 64 items per wave
+    const bool pooled = VARTIME && !direct;
+    const size_t pool_words = VtPool::words(out_form == CHEETAH_PROJECTIVE ? 3 : 4);
     // the ONLY_WIDE instance of the NAF kernel (normally nothing to do) is compiled for 2 waves
-    int grid_vt = lane_grid(ctx, n, direct ? 2 : CH_VT_WAVES), grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
+    int grid_vt = pooled ? lane_grid(ctx, (n + VtPool::SLOTS - 1) / VtPool::SLOTS, CH_VT_POOL_WAVES) : lane_grid(ctx, n, direct ? 2 : CH_VT_WAVES);
+    int grid_ct = lane_grid(ctx, n, CH_CT_WAVES);
     if (arena) {
         if (grid_vt > max_blocks) grid_vt = max_blocks;
         if (grid_ct > max_blocks) grid_ct = max_blocks;
     } else {
-        if (int32_t rc = ensure_scratch(ctx, (size_t)(grid_vt > grid_ct ? grid_vt : grid_ct) * LaneScratch::WORDS_PER_BLOCK)) return rc;
+        size_t words = (size_t)(grid_vt > grid_ct ? grid_vt : grid_ct) * LaneScratch::WORDS_PER_BLOCK;
+        if (pooled) words = (size_t)grid_vt * pool_words;
+        if (int32_t rc = ensure_scratch(ctx, words)) return rc;
         arena = ctx->scratch;
     }
-    const int grid = (VARTIME && !direct) ? grid_vt : grid_ct;
+    const int grid = pooled ? grid_vt : grid_ct;
     // One launch covers at most ctx->launch_rounds rounds of the resident grid (default 2: 17 ms of work at 4 workgroups per CU).
     // The workgroups are persistent within a launch and fill every CU, so a kernel on another stream (the RCCL
     // all-gather of the previous chunk) can only get CU slots at a launch boundary: bounding the launch bounds its wait.
     const size_t in_w = form_limbs(in_form), out_w = form_limbs(out_form);
-    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds;
+    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds * (pooled ? VtPool::SLOTS : 1);
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u64* pts_o = pts + off * in_w;
@@ -1126,8 +1158,8 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
             hipLaunchKernelGGL((k_multiply_vartime<A, I, O, true>), dim3(grid_vt), dim3(BLOCK), 0, ctx->stream, ctx->tables,    \
                                pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                                      \
         } else if constexpr (VARTIME)                                                                                          \
-            hipLaunchKernelGGL((k_multiply_vartime<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,      \
-                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                                      \
+            hipLaunchKernelGGL((k_multiply_vartime_pool<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,        \
+                               pts_o, sc_o, out_o, inf_o, cnt, arena, pool_words);                                             \
         else                                                                                                                   \
             hipLaunchKernelGGL((k_multiply_ct<A, I, O, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,    \
                                sc_o, out_o, inf_o, cnt, arena);                                                                \
@@ -1764,6 +1796,33 @@ extern "C" int32_t cheetah_synth_scalars_dev(cheetah_ctx* ctx, uint64_t seed, ui
     return CHEETAH_OK;
 }
 
+// {Affine,Projective,Jacobian}Point::random with the seeded generator in the rng's place: candidates by
+// k_random_candidates (x drawn, y = +-sqrt(x^3 + x + B)), then clear_cofactor through the fixed-scalar ladder, whose
+// representative is the one the reference's clear_cofactor returns.  Sub-batches of 2^19 bound the temporaries (48 MB).
+// Runs on the context's first device (like the other synthetic-input generators).
+extern "C" int32_t cheetah_random_points_dev(cheetah_ctx* ctx, uint64_t seed, uint64_t start, uint64_t* out, uint8_t* inf, size_t n,
+                                             int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
+    SET_DEVICE(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!out || !aligned16(out) || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "bad pointer");
+    constexpr size_t SUB = (size_t)1 << 19;
+    const size_t cap = n < SUB ? n : SUB;
+    if (int32_t rc = ensure_slot(ctx, ctx->pair_tmp, cap * 258, ctx->stream)) return rc;
+    u64* cand = static_cast<u64*>(ctx->pair_tmp.p);
+    const size_t out_w = form_limbs(out_form);
+    for (size_t off = 0; off < n; off += SUB) {
+        const size_t cnt = n - off < SUB ? n - off : SUB;
+        hipLaunchKernelGGL(k_random_candidates, dim3(ew_grid(ctx, cnt)), dim3(BLOCK), 0, ctx->stream, seed, start + off, cand, cnt);
+        if (int32_t rc = fixed_scalar_impl(ctx, cand, CHEETAH_AFFINE, ctx->fixed_scalars + 32, out + off * out_w, inf ? inf + off : nullptr, cnt,
+                                           out_form))
+            return rc;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CHEETAH_OK;
+}
+
 // ---------------------------------------------------------- diagnostics -----
 
 extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
@@ -1779,8 +1838,9 @@ extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t
 extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n, int vartime, int out_form, size_t* units) {
     if (!ctx) return CHEETAH_ERR_INVALID;
     if (!units) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
-    const int waves = (vartime && out_form != CHEETAH_AFFINE) ? CH_VT_WAVES : CH_CT_WAVES;
-    const size_t per_launch = (size_t)lane_grid(ctx, n ? n : 1, waves) * BLOCK * ctx->launch_rounds;
+    const bool pooled = vartime && out_form != CHEETAH_AFFINE;
+    const size_t slots = pooled ? VtPool::SLOTS : 1;
+    const size_t per_launch = (size_t)lane_grid(ctx, ((n ? n : 1) + slots - 1) / slots, pooled ? CH_VT_POOL_WAVES : CH_CT_WAVES) * BLOCK * slots * ctx->launch_rounds;
     *units = n < per_launch ? n : per_launch;
     return CHEETAH_OK;
 }

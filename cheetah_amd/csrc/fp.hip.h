@@ -313,4 +313,34 @@ CH_DEV u64 fp_invert(u64 a) {
     return fp_mul(t0, a);
 }
 
+// a^power, the square-and-multiply of src/fp.rs:304-333 (exp selects, exp_vartime branches on the exponent bit: the
+// same value; here the exponent is one value for the whole launch, so the branch is uniform).
+CH_DEV u64 fp_exp(u64 a, u64 power) {
+    u64 res = 1;
+    for (int i = 63; i >= 0; i--) {
+        res = fp_square(res);
+        if ((power >> i) & 1) res = fp_mul(res, a);
+    }
+    return res;
+}
+
+// Fp::sqrt, src/fp.rs:199-229: Tonelli-Shanks for 2-adicity 32 in its constant-time form.  Returns the root the
+// reference's algorithm returns (not its negative) and *is_some = (s^2 == a).
+CH_DEV u64 fp_sqrt(u64 a, bool* is_some) {
+    const u64 y = fp_exp(a, 0x7fffffffull);           // the progenitor a^((t - 1) / 2)
+    u64 s = fp_mul(a, y), t = fp_mul(s, y);
+    u64 z = 1753635133440165772ull;                   // TWO_ADIC_ROOT_OF_UNITY, src/fp.rs:48
+    for (int k = 32; k >= 2; k--) {
+        const u64 b = fp_sqn(t, k - 2);
+        const bool is_one = fp_canonical(b) == 1;
+        const u64 new_s = fp_mul(s, z);
+        s = is_one ? s : new_s;
+        z = fp_square(z);
+        const u64 new_t = fp_mul(t, z);
+        t = is_one ? t : new_t;
+    }
+    *is_some = fp_canonical(fp_square(s)) == fp_canonical(a);
+    return s;
+}
+
 }  // namespace cheetah

@@ -384,6 +384,19 @@ CH_DEV Fp6 fp6_sqrt(const Fp6& self, bool* is_some) {
     return x;
 }
 
+// a^power for a 384-bit little-endian exponent: Fp6::exp / exp_vartime, src/fp6.rs:1053-1086 (the same value; the
+// exponent is one value for the whole launch, so the branch on its bits is uniform).
+CH_DEV Fp6 fp6_exp(const Fp6& a, const u64 (&power)[6]) {
+    Fp6 res = fp6_one();
+    for (int w = 5; w >= 0; w--) {
+        for (int i = 63; i >= 0; i--) {
+            res = fp6_square(res);
+            if ((power[w] >> i) & 1) res = fp6_mul(res, a);
+        }
+    }
+    return res;
+}
+
 // a * (3u + 1185) = a * 3B.                          (src/curve/mod.rs:54-106)
 CH_DEV Fp6 fp6_mul_by_3b(const Fp6& a) {
     Fp6 r;

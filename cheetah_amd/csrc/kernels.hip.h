@@ -59,6 +59,14 @@ struct DeviceTables {
 };
 constexpr int WIDE_BITS = 6, WIDE_WINDOWS = 43, WIDE_ENTRIES = 32, WIDE_BLOCK = 1024;
 
+// The counter-based generator of cheetah_amd/synth.py (synthetic inputs, seeded random points).
+CH_DEV u64 splitmix64(u64 seed, u64 idx) {
+    u64 z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 // ---- AoS <-> register helpers --------------------------------------------
 CH_DEV Fp6 load_fp6(const u64* p) {
     Fp6 r;
@@ -325,6 +333,13 @@ CH_DEV void store_fp6_vec_canonical(u64* p, const Fp6& a) {
     q[0] = v0; q[1] = v1; q[2] = v2;
 }
 
+CH_DEV void store_fp6_vec_raw(u64* p, const Fp6& a) {  // limbs as they are (internal state, not an output)
+    u64x2* q = reinterpret_cast<u64x2*>(p);
+    u64x2 v0, v1, v2;
+    v0.x = a.c[0]; v0.y = a.c[1]; v1.x = a.c[2]; v1.y = a.c[3]; v2.x = a.c[4]; v2.y = a.c[5];
+    q[0] = v0; q[1] = v1; q[2] = v2;
+}
+
 template <int OP>
 __global__ void __launch_bounds__(BLOCK) k_fp6_elementwise(const u64* __restrict__ a, const u64* __restrict__ b,
                                                            u64* __restrict__ out, u8* __restrict__ is_some, size_t n) {
@@ -377,9 +392,18 @@ __global__ void __launch_bounds__(BLOCK) k_fp6_op(int op, const u64* __restrict_
     }
 }
 
+// Fp6::exp / exp_vartime over a batch, one exponent for the whole batch (cheetah_fp6_exp_batch).
+__global__ void __launch_bounds__(BLOCK) k_fp6_exp(const u64* __restrict__ a, u64 p0, u64 p1, u64 p2, u64 p3, u64 p4, u64 p5,
+                                                   u64* __restrict__ out, size_t n) {
+    const u64 power[6] = {p0, p1, p2, p3, p4, p5};
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+        store_fp6_vec_canonical(out + 6 * i, fp6_exp(load_fp6_vec(a + 6 * i), power));
+}
+
 // The base-field operations over a batch (cheetah_fp_op_batch): Fp::add / sub / neg / double / triple / mul / square /
 // mul_by_u32 / invert / make_canonical (src/fp.rs:125-196, :335-359).  One element per lane, HBM-bound except invert.
-enum FpOp { FP_ADD = 0, FP_SUB, FP_NEG, FP_DOUBLE, FP_TRIPLE, FP_MUL, FP_SQUARE, FP_MUL_BY_U32, FP_INVERT, FP_CANONICAL, FP_OPS };
+enum FpOp { FP_ADD = 0, FP_SUB, FP_NEG, FP_DOUBLE, FP_TRIPLE, FP_MUL, FP_SQUARE, FP_MUL_BY_U32, FP_INVERT, FP_CANONICAL, FP_SQRT, FP_EXP,
+            FP_OPS };
 __global__ void __launch_bounds__(BLOCK) k_fp_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64 scalar,
                                                  u64* __restrict__ out, u8* __restrict__ is_some, size_t n) {
     const size_t stride = (size_t)gridDim.x * BLOCK;
@@ -396,6 +420,14 @@ __global__ void __launch_bounds__(BLOCK) k_fp_op(int op, const u64* __restrict__
             case FP_SQUARE: r = fp_square(x); break;
             case FP_MUL_BY_U32: r = fp_mul(x, scalar & 0xffffffffull); break;
             case FP_INVERT: r = fp_invert(x); break;  // 0 -> 0, flagged none (CtOption, src/fp.rs:335-359)
+            case FP_SQRT: {                           // Fp::sqrt, src/fp.rs:199-229; a non-square leaves as 0 with is_some = 0
+                bool some;
+                r = fp_sqrt(x, &some);
+                if (!some) r = 0;
+                if (is_some) is_some[i] = some ? 1 : 0;
+                break;
+            }
+            case FP_EXP: r = fp_exp(x, scalar); break;  // Fp::exp / exp_vartime, src/fp.rs:304-333
             default: r = x; break;
         }
         out[i] = fp_canonical(r);
@@ -1183,6 +1215,229 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
 
 
 // ---------------------------------------------------------------------------
+// multiply_vartime with the reference's own representative (L2), pooled: the NAF ladder of k_multiply_vartime with
+// every WAVE owning SLOTS x 64 scalar multiplications instead of 64.  Each item still runs ITS OWN reference sequence
+// (256 doublings, an addition after each non-zero width-5 NAF digit, then - 2^256 S; src/curve/projective.rs:633-662,
+// src/curve/jacobian.rs:619-649, quirk Q1), so the (X, Y, Z) it ends with is the reference's; what the wave schedules is
+// which 64 of its items take the next step together.  With one item per lane (k_multiply_vartime) a doubling phase
+// keeps ~ 73 % of the lanes busy and an addition phase ~ 78 %, because at every position some lane has a non-zero
+// digit; with a pool of 128 a phase is full except at the very end of a round (tools/naf_pool_sim.py: 97 - 99 % of the
+// lane-slots used, 329 phase-units per 64 items against 440; on the device 99.6 % / 99.0 % of the lanes of a doubling /
+// addition phase, 257 + 43 phases per 64 items).  The price is that an item's accumulator lives in global scratch
+// between its steps (AccIO: one contiguous record per item, 16-byte accesses) and is loaded / stored around every
+// step: 2 x 144 (192) bytes per step and lane.
+// Everything an item owns -- its NAF in LDS, its table and accumulator in scratch, its position and parked digit in
+// LDS -- belongs to ONE wave, so the scheduling loop has no barrier, no lock and no wait on another wave: every phase
+// completes at least one step of one item, which bounds a round by SLOTS * 64 * (256 + 52) phases (a non-zero NAF digit
+// is followed by four zeros).  The loop enforces that bound and flags what is unfinished (zero limbs, inf = 0xFE)
+// instead of spinning.
+//   phase policy (the model in tools/naf_pool_sim.py, statement for statement):
+//     additions if >= 64 items are parked at a non-zero digit, else doublings if >= 64 can double, else the larger group;
+//     among the candidates those at or above the candidates' mean position first (the laggards), slots and lanes in an
+//     order that rotates with the phase number.
+#ifndef CH_VT_SLOTS
+#define CH_VT_SLOTS 2
+#endif
+// Measured (tools/lab/vt_lab.py, 2^22, affine in; parked = k_multiply_vartime): projective representative 18.5 M/s parked,
+// pooled 21.7 at 3 waves per SIMD and 2 slots (20.8 at 4 waves, 20.6 with 3 slots, 20.8 with the accumulators SoA like the
+// tables, 20.9 with the doublings through calls); Jacobian representative 23.1 parked, pooled 24.9 (14.3 at 4 waves, where
+// the loop spills).  With no accumulator traffic at all the pooled schedule would reach 24.8 / 30.5: its loads and its
+// stores each cost ~ 6 % (SQ_INSTS_VALU + 9 % per phase for addresses, packing and the scheduling itself).
+#ifndef CH_VT_POOL_WAVES
+#define CH_VT_POOL_WAVES 3
+#endif
+#ifdef LAB_COUNT
+__device__ unsigned long long lab_counters[4];  // tools/lab only: doubling phases, addition phases, lanes used in each
+#endif
+struct VtPool {
+    static constexpr int SLOTS = CH_VT_SLOTS;
+    static constexpr size_t TAB = (size_t)8 * 12 * BLOCK;   // NafLookupTable<8> per slot
+    static constexpr size_t ZP = (size_t)8 * 6 * BLOCK;     // z / prefix of the table build (shared by the slots)
+    static size_t words(int n_fp6) { return SLOTS * TAB + 2 * ZP + (size_t)SLOTS * n_fp6 * 6 * BLOCK; }
+    static constexpr int phase_bound() { return SLOTS * 64 * (256 + 52); }
+};
+CH_DEV int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// rank of `lane` among the set bits of m, counted from lane r upwards (wrapping)
+CH_DEV int rotated_rank(u64 m, int r, int lane) {
+    const u64 rot = r ? ((m >> r) | (m << (64 - r))) : m;
+    const int lr = (lane - r) & 63;
+    return __builtin_popcountll(rot & ((1ull << lr) - 1ull));
+}
+// An item's accumulator in scratch: NF x 48 contiguous bytes per item (AoS, [slot][owner lane][limb]), moved by 16-byte
+// accesses -- a phase's lanes read whole items, so the layout that coalesces is the one that keeps an item together.
+// (Measured, tools/lab/vt_lab.py: the SoA form of the window tables, 8-byte gathers at [limb][lane], costs the pooled
+// kernel 1.7 us of SIMD time per phase: 20.8 M/s against 24.8 with no state traffic at all.)
+template <class ACC> struct AccIO;
+template <> struct AccIO<Proj> {
+    static constexpr int NF = 3;
+    static CH_DEV void store(u64* st, const Proj& a, int tt) {
+        u64* p = st + (size_t)tt * (NF * 6);
+        store_fp6_vec_raw(p, a.x); store_fp6_vec_raw(p + 6, a.y); store_fp6_vec_raw(p + 12, a.z);
+    }
+    static CH_DEV Proj load(const u64* st, int tt) {
+        const u64* p = st + (size_t)tt * (NF * 6);
+        Proj a; a.x = load_fp6_vec(p); a.y = load_fp6_vec(p + 6); a.z = load_fp6_vec(p + 12); return a;
+    }
+};
+template <> struct AccIO<MJac> {
+    static constexpr int NF = 4;
+    static CH_DEV void store(u64* st, const MJac& a, int tt) {
+        u64* p = st + (size_t)tt * (NF * 6);
+        store_fp6_vec_raw(p, a.x); store_fp6_vec_raw(p + 6, a.y); store_fp6_vec_raw(p + 12, a.z); store_fp6_vec_raw(p + 18, a.z4);
+    }
+    static CH_DEV MJac load(const u64* st, int tt) {
+        const u64* p = st + (size_t)tt * (NF * 6);
+        MJac a; a.x = load_fp6_vec(p); a.y = load_fp6_vec(p + 6); a.z = load_fp6_vec(p + 12); a.z4 = load_fp6_vec(p + 18); return a;
+    }
+};
+
+template <class ACC, int IN_FORM, int OUT_FORM>
+__global__ void __launch_bounds__(BLOCK, CH_VT_POOL_WAVES) k_multiply_vartime_pool(const DeviceTables* __restrict__ tab,
+                                                            const u64* __restrict__ pts, const u8* __restrict__ scalars,
+                                                            u64* __restrict__ out, u8* __restrict__ inf, size_t n,
+                                                            u64* __restrict__ scratch, size_t words_per_block) {
+    constexpr int SLOTS = VtPool::SLOTS, NF = AccIO<ACC>::NF;
+    __shared__ u8 s_naf[SLOTS * 64 * BLOCK];
+    __shared__ short s_pos[SLOTS * BLOCK];
+    __shared__ i8 s_pd[SLOTS * BLOCK];
+    __shared__ u8 s_ident[SLOTS * BLOCK];
+    __shared__ u8 s_list[BLOCK];
+    const int t = threadIdx.x, lane = t & 63, wbase = t & ~63;
+    u64* base = scratch + (size_t)blockIdx.x * words_per_block;
+    u64* s_z = base + SLOTS * VtPool::TAB;
+    u64* s_prefix = s_z + VtPool::ZP;
+    u64* state0 = s_prefix + VtPool::ZP;
+    const Affine shift = load_affine(tab->shift);
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t per_round = (size_t)SLOTS * BLOCK;
+    const size_t nround = (n + per_round - 1) / per_round;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        // ---- set-up: lane t owns item round * SLOTS * BLOCK + s * BLOCK + t of every slot s ----
+        __syncthreads();
+        for (int s = 0; s < SLOTS; s++) {
+            const size_t i = round * per_round + (size_t)s * BLOCK + t;
+            const bool active = i < n;
+            const size_t ii = active ? i : n - 1;
+            u64 k[4];
+            load_scalar(scalars, ii, k);
+            recode_wnaf5_packed(k, s_naf + (size_t)s * 64 * BLOCK, t);
+            s_pos[s * BLOCK + t] = active ? (short)255 : (short)-1;
+            s_pd[s * BLOCK + t] = 0;
+            if (__any(active)) {
+                const Proj p = load_input_point<IN_FORM>(pts, ii);
+                s_ident[s * BLOCK + t] = (u8)build_table<true>(p, 8, base + s * VtPool::TAB, s_z, s_prefix, t);
+                AccIO<ACC>::store(state0 + (size_t)s * NF * 6 * BLOCK, Ladder<ACC>::from_affine(shift), t);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- the wave's scheduling loop: no barrier, nothing shared with another wave ----
+        int phase = 0;
+        for (;; phase++) {
+            int pos_s[SLOTS], pd_s[SLOTS];
+            u64 m_d[SLOTS], m_a[SLOTS];
+            int n_d = 0, n_a = 0;
+#pragma unroll
+            for (int s = 0; s < SLOTS; s++) {
+                pos_s[s] = s_pos[s * BLOCK + t];
+                pd_s[s] = s_pd[s * BLOCK + t];
+                m_d[s] = __builtin_amdgcn_ballot_w64(pd_s[s] == 0 && pos_s[s] >= 0);
+                m_a[s] = __builtin_amdgcn_ballot_w64(pd_s[s] != 0);
+                n_d += __builtin_popcountll(m_d[s]);
+                n_a += __builtin_popcountll(m_a[s]);
+            }
+            if ((n_d == 0 && n_a == 0) || phase >= VtPool::phase_bound()) break;
+            const bool add = n_a >= 64 || (n_d < 64 && n_a > n_d);
+            const int cnt = add ? n_a : n_d;
+            // the candidates at or above their mean position go first
+            int mine = 0;
+#pragma unroll
+            for (int s = 0; s < SLOTS; s++) {
+                const bool want = add ? pd_s[s] != 0 : (pd_s[s] == 0 && pos_s[s] >= 0);
+                mine += want ? pos_s[s] : 0;
+            }
+            const int sum = wave_sum_i32(mine);
+            u64 m_hi[SLOTS], m_lo[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; s++) {
+                const bool want = add ? pd_s[s] != 0 : (pd_s[s] == 0 && pos_s[s] >= 0);
+                m_hi[s] = __builtin_amdgcn_ballot_w64(want && pos_s[s] * cnt >= sum);
+                m_lo[s] = (add ? m_a[s] : m_d[s]) & ~m_hi[s];
+            }
+            const int r = (phase * 17) & 63;
+            int offset = 0;
+#pragma unroll
+            for (int tier = 0; tier < 2; tier++) {
+#pragma unroll
+                for (int o = 0; o < SLOTS; o++) {
+                    const int s = (o + phase) % SLOTS;
+                    const u64 m = tier == 0 ? m_hi[s] : m_lo[s];
+                    if ((m >> lane) & 1ull) {
+                        const int p = offset + rotated_rank(m, r, lane);
+                        if (p < 64) s_list[wbase + p] = (u8)((s << 6) | lane);
+                    }
+                    offset += __builtin_popcountll(m);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int take = cnt < 64 ? cnt : 64;
+#ifdef LAB_COUNT
+            if (lane == 0) {
+                atomicAdd(&lab_counters[add ? 1 : 0], 1ull);
+                atomicAdd(&lab_counters[add ? 3 : 2], (unsigned long long)take);
+            }
+#endif
+            if (lane < take) {
+                const int code = s_list[wbase + lane];
+                const int s = code >> 6, tt = wbase + (code & 63);
+                u64* st = state0 + (size_t)s * NF * 6 * BLOCK;
+                ACC acc = AccIO<ACC>::load(st, tt);
+                if (add) {
+                    const int pd = s_pd[s * BLOCK + tt];
+                    const int e = (pd < 0 ? -pd : pd) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
+                    const u64* tb = base + s * VtPool::TAB;
+                    Affine q;
+                    q.x = sc_load(tb, e, 0, tt, 12);
+                    q.y = sc_load(tb, e, 6, tt, 12);
+                    q.inf = (s_ident[s * BLOCK + tt] >> e) & 1;
+                    acc = Ladder<ACC>::add(acc, affine_cond_neg(q, pd < 0));
+                    s_pd[s * BLOCK + tt] = 0;
+                } else {
+                    acc = Ladder<ACC>::dbl_inl(acc);
+                    const int p = s_pos[s * BLOCK + tt];
+                    s_pd[s * BLOCK + tt] = (i8)naf4_digit(s_naf + (size_t)s * 64 * BLOCK, p, tt);
+                    s_pos[s * BLOCK + tt] = (short)(p - 1);
+                }
+                AccIO<ACC>::store(st, acc, tt);
+            }
+            __threadfence_block();  // the accumulators just stored are read by other lanes of this wave in a later phase
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- the owners close their items: - 2^256 S, emit ----
+        for (int s = 0; s < SLOTS; s++) {
+            const size_t i = round * per_round + (size_t)s * BLOCK + t;
+            if (i < n) {
+                const bool finished = s_pos[s * BLOCK + t] < 0 && s_pd[s * BLOCK + t] == 0;
+                ACC acc = AccIO<ACC>::load(state0 + (size_t)s * NF * 6 * BLOCK, t);
+                acc = Ladder<ACC>::add(acc, mshift);
+                if (finished) {
+                    emit_point<OUT_FORM>(out, inf, i, acc);
+                } else {  // the phase bound was hit: flagged, never silently wrong
+                    const int width = OUT_FORM == 0 ? 12 : 18;
+                    for (int l = 0; l < width; l++) out[(size_t)width * i + l] = 0;
+                    if (inf) inf[i] = 0xFE;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Multi-scalar (Straus) ladders: out[g] = sum_{j<m} k[g][j] * P[g][j], shared
 // doublings, one window table per point, additions in index order.
 //   ct      ProjectivePoint / JacobianPoint::multiply_many  src/curve/projective.rs:817-832, src/curve/jacobian.rs:807-823
@@ -1564,6 +1819,35 @@ __global__ void __launch_bounds__(BLOCK) k_affine_from_x(const u64* __restrict__
     }
 }
 
+// The first half of {Affine,Projective,Jacobian}Point::random (src/curve/projective.rs:228-248, jacobian.rs:247-267,
+// affine.rs:243-245) with the rng replaced by the seeded counter generator: element i owns the draws
+// d(i, j) = splitmix64(seed, (start + i) * 256 + j); attempt a takes x = (d(i, 7a) % p, ..., d(i, 7a + 5) % p) (Fp6::random,
+// src/fp6.rs:385-394) and flip_sign = d(i, 7a + 6) as a u32 is odd; the first attempt whose x^3 + x + B is a square gives
+// (x, +-sqrt) -- the reference's loop.  cheetah_random_points_dev then clears the cofactor (fixed-scalar ladder).
+// 36 attempts fit the 256 draws; an element that found none (probability 2^-36) leaves as the identity encoding (0, 1).
+constexpr int RANDOM_MAX_ATTEMPTS = 36;
+__global__ void __launch_bounds__(BLOCK) k_random_candidates(u64 seed, u64 start, u64* __restrict__ xy, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Affine p = affine_identity();
+        const u64 base = (start + i) * 256ull;
+        for (int a = 0; a < RANDOM_MAX_ATTEMPTS; a++) {
+            Fp6 x;
+#pragma unroll
+            for (int l = 0; l < 6; l++) x.c[l] = fp_canonical(splitmix64(seed, base + 7 * a + l));
+            const bool flip = (u32)splitmix64(seed, base + 7 * a + 6) & 1u;
+            bool ok;
+            Fp6 y = fp6_sqrt(curve_rhs(x), &ok);
+            if (ok) {
+                p.x = x;
+                p.y = flip ? fp6_neg(y) : y;
+                break;
+            }
+        }
+        store_fp6_vec_canonical(xy + 12 * i, p.x);
+        store_fp6_vec_canonical(xy + 12 * i + 6, p.y);
+    }
+}
+
 // A record rejected by the subgroup check leaves as (0, 0, inf = 0) like every other none.
 __global__ void __launch_bounds__(BLOCK) k_zero_rejected(u64* __restrict__ xy, u8* __restrict__ inf, const u8* __restrict__ is_some,
                                                          size_t n) {
@@ -1674,12 +1958,6 @@ __global__ void __launch_bounds__(BLOCK) k_point_eq(const u64* __restrict__ a, c
 
 // ---------------------------------------------------------------------------
 // Synthetic inputs: the generator of cheetah_amd/synth.py on the device.
-CH_DEV u64 splitmix64(u64 seed, u64 idx) {
-    u64 z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 __global__ void __launch_bounds__(BLOCK) k_synth_fp6(u64 seed, u64 start, u64* out, size_t n_words) {
     for (size_t w = (size_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (size_t)gridDim.x * BLOCK)
         out[w] = fp_canonical(splitmix64(seed, 6 * start + w));

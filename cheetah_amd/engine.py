@@ -126,11 +126,12 @@ class Engine:
         self._check(self._lib.cheetah_fp6_square_batch(self._h, a.ctypes.data, out.ctypes.data, len(a)))
         return out
 
-    FP_OPS = ("add", "sub", "neg", "double", "triple", "mul", "square", "mul_by_u32", "invert", "canonical")
+    FP_OPS = ("add", "sub", "neg", "double", "triple", "mul", "square", "mul_by_u32", "invert", "canonical", "sqrt", "exp")
 
     def fp_op_batch(self, op, a, b=None, scalar=0):
         """out[i] = op(a[i] [, b[i] | scalar]) in the base field, one u64 per element (src/fp.rs:125-196, :335-359); op is one
-        of Engine.FP_OPS.  "invert" returns (out, is_some)."""
+        of Engine.FP_OPS.  "invert" and "sqrt" (Fp::sqrt, src/fp.rs:199-229) return (out, is_some); "exp" (Fp::exp, :304-333) raises
+        to the power `scalar`."""
         code = self.FP_OPS.index(op)
         binary = op in ("add", "sub", "mul")
         if binary and b is None:
@@ -142,11 +143,11 @@ class Engine:
             if binary and b.shape != a.shape:
                 raise ValueError("shape mismatch")
             out = self._empty(a.shape, torch.uint64)
-            some = self._empty(a.shape, torch.uint8) if op == "invert" else None
+            some = self._empty(a.shape, torch.uint8) if op in ("invert", "sqrt") else None
             self._use_torch_stream()
             self._check(self._lib.cheetah_fp_op_batch_dev(self._h, code, a.data_ptr(), bp, int(scalar), out.data_ptr(),
                                                           some.data_ptr() if some is not None else 0, a.shape[0]))
-            return (out, some) if op == "invert" else out
+            return (out, some) if some is not None else out
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
         bp = 0
         if binary:
@@ -155,10 +156,10 @@ class Engine:
                 raise ValueError("shape mismatch")
             bp = b.ctypes.data
         out = np.empty_like(a)
-        some = np.empty(len(a), np.uint8) if op == "invert" else None
+        some = np.empty(len(a), np.uint8) if op in ("invert", "sqrt") else None
         self._check(self._lib.cheetah_fp_op_batch(self._h, code, a.ctypes.data, bp, int(scalar), out.ctypes.data,
                                                   some.ctypes.data if some is not None else 0, len(a)))
-        return (out, some) if op == "invert" else out
+        return (out, some) if some is not None else out
 
     FP6_OPS = ("add", "sub", "neg", "double", "triple", "mul_by_u32", "mul_by_fp", "canonical", "frobenius", "frobenius_double",
                "frobenius_triple", "mul_by_3b")
@@ -192,6 +193,29 @@ class Engine:
         out = np.empty_like(a)
         self._check(self._lib.cheetah_fp6_op_batch(self._h, code, a.ctypes.data, bp, int(scalar), out.ctypes.data, len(a)))
         return out
+
+    def fp6_exp_batch(self, a, power):
+        """out[i] = a[i]^power for one exponent < 2^384 (Fp6::exp / exp_vartime, src/fp6.rs:1053-1086)."""
+        pw = (C.c_uint64 * 6)(*[(int(power) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)])
+        if _is_torch(a):
+            x = self._dev(a, 8, 6)
+            out = self._empty(x.shape, torch.uint64)
+            self._use_torch_stream()
+            self._check(self._lib.cheetah_fp6_exp_batch_dev(self._h, x.data_ptr(), C.addressof(pw), out.data_ptr(), x.shape[0]))
+            return out
+        x = self._np(a, np.uint64, 6)
+        out = np.empty_like(x)
+        self._check(self._lib.cheetah_fp6_exp_batch(self._h, x.ctypes.data, C.addressof(pw), out.ctypes.data, len(x)))
+        return out
+
+    def random_points(self, seed, n, start=0, out_form=AFFINE):
+        """n seeded points of the prime-order subgroup shaped like {Affine,Projective,Jacobian}Point::random
+        (src/curve/projective.rs:228-248): x drawn, y = +-sqrt(x^3 + x + B), cofactor cleared.  Device tensors (out, inf)."""
+        w = self._out_width(out_form)
+        out, inf = self._empty((n, w), torch.uint64), self._empty((n,), torch.uint8)
+        self._use_torch_stream()
+        self._check(self._lib.cheetah_random_points_dev(self._h, int(seed), int(start), out.data_ptr(), inf.data_ptr(), n, out_form))
+        return out, inf
 
     def _fp6_option(self, name, a):
         if _is_torch(a):

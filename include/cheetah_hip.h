@@ -90,10 +90,12 @@ const char *cheetah_version(void);
  * canonical output; b is read by ADD / SUB / MUL, scalar (low 32 bits) by MUL_BY_U32; INVERT maps 0 to 0 and, if is_some is
  * not NULL, sets is_some[i] = 0 there (CtOption::none) and 1 elsewhere:
  *   ADD SUB NEG DOUBLE TRIPLE   src/fp.rs:136-174      MUL SQUARE MUL_BY_U32   src/fp.rs:178-196 (reduce_u128 / reduce_u96, :623-667)
- *   INVERT                      src/fp.rs:335-359      CANONICAL (make_canonical)   src/fp.rs:125-127 */
+ *   INVERT                      src/fp.rs:335-359      CANONICAL (make_canonical)   src/fp.rs:125-127
+ *   SQRT  Fp::sqrt (src/fp.rs:199-229): the root the reference's Tonelli-Shanks returns; a non-square gives out = 0 and
+ *         is_some[i] = 0 (is_some may be NULL)         EXP  Fp::exp / exp_vartime (src/fp.rs:304-333): a[i]^scalar, scalar a u64 */
 typedef enum {
     CHEETAH_FP_ADD = 0, CHEETAH_FP_SUB, CHEETAH_FP_NEG, CHEETAH_FP_DOUBLE, CHEETAH_FP_TRIPLE, CHEETAH_FP_MUL, CHEETAH_FP_SQUARE,
-    CHEETAH_FP_MUL_BY_U32, CHEETAH_FP_INVERT, CHEETAH_FP_CANONICAL
+    CHEETAH_FP_MUL_BY_U32, CHEETAH_FP_INVERT, CHEETAH_FP_CANONICAL, CHEETAH_FP_SQRT, CHEETAH_FP_EXP
 } cheetah_fp_op;
 int32_t cheetah_fp_op_batch(cheetah_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t scalar, uint64_t *out,
                             uint8_t *is_some, size_t n);
@@ -128,6 +130,10 @@ int32_t cheetah_fp6_square_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64
 int32_t cheetah_fp6_invert_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
 int32_t cheetah_fp6_sqrt_batch(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
 int32_t cheetah_fp6_sqrt_batch_dev(cheetah_ctx *ctx, const uint64_t *a, uint64_t *out, uint8_t *is_some, size_t n);
+/* out[i] = a[i]^power       Fp6::exp / Fp6::exp_vartime   src/fp6.rs:1053-1086 (the two return the same element);
+ * power6: HOST pointer (also for `_dev`) to the 6 little-endian 64-bit limbs of ONE exponent for the whole batch. */
+int32_t cheetah_fp6_exp_batch(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *power6, uint64_t *out, size_t n);
+int32_t cheetah_fp6_exp_batch_dev(cheetah_ctx *ctx, const uint64_t *a, const uint64_t *power6, uint64_t *out, size_t n);
 
 /* ---- batch_normalize -----------------------------------------------------
  * xy[i], inf[i] = affine form of xyz[i]; identities (z = 0) give (0, 1, inf = 1).
@@ -386,6 +392,16 @@ int32_t cheetah_read_table(cheetah_ctx *ctx, int which, uint64_t *out_xy, size_t
  * (the reference draws from OsRng, e.g. benches/fp6.rs:23-29). */
 int32_t cheetah_synth_fp6_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint64_t *out, size_t n);
 int32_t cheetah_synth_scalars_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint8_t *out32, size_t n);
+/* Seeded points of the prime-order subgroup shaped like the reference's `random()`:
+ *   ProjectivePoint::random  src/curve/projective.rs:228-248   JacobianPoint::random  src/curve/jacobian.rs:247-267
+ *   AffinePoint::random      src/curve/affine.rs:243-245       (out_form selects; PROJECTIVE / JACOBIAN give the
+ *   representative clear_cofactor() = multiply_vartime(h) returns, AFFINE its affine point)
+ * with the rng replaced by the counter generator: element i draws d(i, j) = splitmix64(seed, (start + i) * 256 + j); attempt
+ * a = 0, 1, ... takes x = (d(i, 7a) % p, ..., d(i, 7a + 5) % p) (Fp6::random) and flip_sign = low 32 bits of d(i, 7a + 6) odd;
+ * the first attempt whose x^3 + x + B is a square gives (x, y or -y), y = Fp6::sqrt(...); then clear_cofactor.  The
+ * reference retries on the identity; here that element (probability ~ 2^-255), or one with no square among its 36
+ * attempts (2^-36), is returned as the identity (inf = 1).  Device pointers, 16-byte aligned; inf required for AFFINE. */
+int32_t cheetah_random_points_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint64_t *out, uint8_t *inf, size_t n, int out_form);
 
 /* ---- diagnostics -----------------------------------------------------------
  * Unit-level parity hook: applies ONE device function to n operand tuples.

@@ -49,6 +49,10 @@ def lib():
         "ora_fp_mul_by_u32": (C.c_uint64, [C.c_uint64, C.c_uint32]),
         "ora_fp_canonical": (C.c_uint64, [C.c_uint64]),
         "ora_fp_invert": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint64)]),
+        "ora_fp_exp": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "ora_fp_sqrt": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint64)]),
+        "ora_fp6_exp": (None, [u64p, u64p, u64p]),
+        "ora_fp6_exp_batch": (None, [u64p, u64p, u64p, C.c_size_t]),
         "ora_reduce_u128": (C.c_uint64, [C.c_uint64, C.c_uint64]),
         "ora_reduce_u96": (C.c_uint64, [C.c_uint64, C.c_uint32]),
         "ora_fp6_add": (None, [u64p, u64p, u64p]),
@@ -370,3 +374,23 @@ def add_mixed_unchecked_batch(lhs, form, rhs_xy):
     out = np.empty_like(a)
     lib().ora_add_mixed_unchecked_batch(a, form, b, out, len(a))
     return out
+
+
+def fp6_exp_batch(a, power):
+    """Fp6::exp over a batch, one exponent < 2^384 (src/fp6.rs:1053-1086)."""
+    a = _u64(a).reshape(-1, 6)
+    pw = np.array([(int(power) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)], np.uint64)
+    out = np.empty_like(a)
+    lib().ora_fp6_exp_batch(a, pw, out, len(a))
+    return out
+
+
+def fp_sqrt(a):
+    """Fp::sqrt (src/fp.rs:199-229): (root, is_some) per element."""
+    a = _u64(a).reshape(-1)
+    out, some = np.zeros(len(a), np.uint64), np.zeros(len(a), np.uint8)
+    r = C.c_uint64()
+    for i, v in enumerate(a):
+        some[i] = lib().ora_fp_sqrt(int(v), C.byref(r))
+        out[i] = r.value
+    return out, some

@@ -145,6 +145,36 @@ int ora_fp_invert(u64 a, u64 *out) {
     if (!s) *out = 0;
     return s;
 }
+/* Fp::exp, src/fp.rs:304-315 (exp_vartime, :323-333, returns the same element) */
+static u64 fp_exp(u64 self, u64 power) {
+    u64 res = 1;
+    for (int i = 63; i >= 0; i--) {
+        res = fp_square(res);
+        u64 tmp = fp_mul(res, self);
+        if ((power >> i) & 1) res = tmp; /* conditional_assign */
+    }
+    return res;
+}
+u64 ora_fp_exp(u64 a, u64 power) { return fp_canonical(fp_exp(a, power)); }
+/* Fp::sqrt, src/fp.rs:199-229: Tonelli-Shanks, constant-time form; returns is_some */
+int ora_fp_sqrt(u64 self, u64 *out) {
+    u64 y = fp_exp(self, 0x7fffffffULL);
+    u64 s = fp_mul(self, y);
+    u64 t = fp_mul(s, y);
+    u64 z = 1753635133440165772ULL; /* TWO_ADIC_ROOT_OF_UNITY, src/fp.rs:48 */
+    for (int k = 32; k >= 2; k--) {
+        u64 b = fp_sqn(t, k - 2);
+        int is_one = fp_canonical(b) == 1;
+        u64 new_s = fp_mul(s, z);
+        s = is_one ? s : new_s;
+        z = fp_square(z);
+        u64 new_t = fp_mul(t, z);
+        t = is_one ? t : new_t;
+    }
+    int some = fp_canonical(fp_square(s)) == fp_canonical(self);
+    *out = some ? fp_canonical(s) : 0;
+    return some;
+}
 u64 ora_reduce_u128(u64 lo, u64 hi) { return reduce_u128(((u128)hi << 64) | lo); }
 u64 ora_reduce_u96(u64 lo, uint32_t hi) { return reduce_u96(((u128)hi << 64) | lo); }
 
@@ -1752,6 +1782,21 @@ static int fp6_sqrt(fp6 self, fp6 *out) {
     if (!is_one) x = fp6_mul_by_high_fp3(x, E);
     *out = x;
     return fp6_eq(fp6_square(x), self);
+}
+/* Fp6::exp, src/fp6.rs:1053-1066 (square, multiply, conditional_assign per bit; exp_vartime returns the same element) */
+void ora_fp6_exp(const u64 *a, const u64 *power6, u64 *o) {
+    fp6 x = fp6_load(a), res = FP6_ONE;
+    for (int w = 5; w >= 0; w--)
+        for (int i = 63; i >= 0; i--) {
+            res = fp6_square(res);
+            fp6 tmp = fp6_mul(res, x);
+            if ((power6[w] >> i) & 1) res = tmp;
+        }
+    fp6_store(o, fp6_canonical(res));
+}
+void ora_fp6_exp_batch(const u64 *a, const u64 *power6, u64 *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) ora_fp6_exp(a + 6 * i, power6, out + 6 * i);
 }
 int ora_fp6_sqrt(const u64 *a, u64 *o) {
     fp6 r;

@@ -42,6 +42,10 @@ uint64_t ora_fp_square(uint64_t a);
 uint64_t ora_fp_mul_by_u32(uint64_t a, uint32_t b);
 uint64_t ora_fp_canonical(uint64_t a);
 int ora_fp_invert(uint64_t a, uint64_t *out); /* returns is_some */
+uint64_t ora_fp_exp(uint64_t a, uint64_t power);   /* src/fp.rs:304-333 */
+int ora_fp_sqrt(uint64_t a, uint64_t *out);        /* src/fp.rs:199-229; returns is_some */
+void ora_fp6_exp(const uint64_t *a, const uint64_t *power6, uint64_t *o); /* src/fp6.rs:1053-1086 */
+void ora_fp6_exp_batch(const uint64_t *a, const uint64_t *power6, uint64_t *out, size_t n);
 uint64_t ora_reduce_u128(uint64_t lo, uint64_t hi);
 uint64_t ora_reduce_u96(uint64_t lo, uint32_t hi);
 

@@ -971,6 +971,22 @@ def test_compress_decompress_round_trip_large(eng):
 
 # ----------------------------------------- BASELINE-size property checks ----
 
+def _golden_block_sums(name):
+    """tests/golden/fullsize_<name>.json: per-2^20-block wrap-around sums of the ORACLE's output over the whole seeded
+    input of a BASELINE configuration (tests/golden/generate_fullsize.py, CPU only)."""
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize_%s.json" % name)) as f:
+        g = json.load(f)
+    assert g["block"] == 1 << 20 and "oracle" in g["pinned_by"]
+    return g
+
+
+def _block_sums(t):
+    """wrap-around 64-bit sums of the limbs of every 2^20-element block of a device array (rows = elements)"""
+    import torch
+    v = t.view(torch.int64)
+    return ["%016x" % (int(x) & 0xFFFFFFFFFFFFFFFF) for x in v.reshape(v.shape[0] >> 20, -1).sum(dim=1).tolist()]
+
+
 def test_full_size_configs_2_3_properties(eng, ora):
     """BASELINE configs 2 and 3 at full size (2^22): a strided sample is compared
     with the oracle, and the whole batch through size-independent properties:
@@ -982,6 +998,8 @@ def test_full_size_configs_2_3_properties(eng, ora):
     S = eng.synth_scalars(2, n)
     pts, inf = eng.mul_by_generator_batch(S, AFFINE)             # config 2
     assert int(inf.sum()) == 0
+    g2 = _golden_block_sums("config2")                           # ALL 2^22 results against the oracle's block sums
+    assert _block_sums(pts) == g2["block_sums"] and g2["blocks"] == 4
     idx = np.arange(0, n, n // 64)
     sc_s = host(S)[idx]
     wxy, _ = ora.mul_by_generator_batch(sc_s, 0)
@@ -990,6 +1008,8 @@ def test_full_size_configs_2_3_properties(eng, ora):
     r_vt, i_vt = eng.multiply_vartime_batch(pts, K, AFFINE, AFFINE)  # config 3
     r_ct, i_ct = eng.multiply_batch(pts, K, AFFINE, AFFINE)
     assert torch.equal(r_vt.view(torch.int64), r_ct.view(torch.int64)) and torch.equal(i_vt, i_ct)
+    g3 = _golden_block_sums("config3")
+    assert _block_sums(r_vt) == g3["block_sums"] and int(i_vt.sum()) == sum(g3["identities_per_block"])
     wxy, winf = ora.multiply_batch(host(pts)[idx], 0, host(K)[idx], 0, vartime=True)
     assert (host(r_vt)[idx] == wxy).all() and (host(i_vt)[idx] == winf).all()
     qb = torch.from_numpy(np.frombuffer(Q.to_bytes(32, "little"), np.uint8).copy()).cuda().repeat(n, 1).contiguous()
@@ -1008,13 +1028,17 @@ def test_full_size_configs_2_3_properties(eng, ora):
 
 def test_full_size_config5_properties(eng, ora):
     """BASELINE config 5 at full size (2^26 seeded (P_i, k_i), bench.py's inputs), in four blocks of 2^24:
-    constant-time == variable-time for ALL i (scan vs indexed lookups), a strided sample against the oracle,
-    no identities, and the wrap-around sum of all canonical limbs equals the committed golden checksum
-    (tests/golden/config5_checksum.json; bench.py prints the same figure) -- a checksum of checksums over the blocks."""
+    the wrap-around sum of the canonical limbs of EVERY 2^20-block of results equals the sum the ORACLE produced for
+    that block on the CPU (tests/golden/fullsize_config5.json, written by tests/golden/generate_fullsize.py: the oracle
+    run over all 2^26 pairs, no GPU involved), constant-time == variable-time for ALL i (scan vs indexed lookups), a
+    strided sample against the oracle, no identities; the sum of the block sums is the figure bench.py prints as
+    `checksum` (tests/golden/config5_checksum.json)."""
     import torch
     from cheetah_amd import AFFINE
     m, blocks = 1 << 24, 4
     total = 0
+    gold = _golden_block_sums("config5")
+    assert gold["blocks"] == 64 and sum(gold["identities_per_block"]) == 0
     for c in range(blocks):
         r = eng.synth_scalars(5, m, (1 << 26) + c * m)
         pts, pinf = eng.mul_by_generator_batch(r, AFFINE)
@@ -1024,10 +1048,14 @@ def test_full_size_config5_properties(eng, ora):
         assert torch.equal(ct.view(torch.int64), vt.view(torch.int64)) and torch.equal(ict, ivt)
         assert int(ict.sum()) == 0 and int(pinf.sum()) == 0
         total = (total + int(ct.view(torch.int64).sum().item())) & 0xFFFFFFFFFFFFFFFF
+        sums = _block_sums(ct)
+        bad = [16 * c + b for b in range(16) if sums[b] != gold["block_sums"][16 * c + b]]
+        assert not bad, "2^20-blocks whose results differ from the oracle's: %r" % bad
         idx = torch.arange(c, m, m // 16, device="cuda")
         wxy, winf = ora.multiply_batch(host(take(pts, idx)), 0, host(take(K, idx)), 0)
         assert (host(take(ct, idx)) == wxy).all() and not winf.any()
         del r, pts, K, ct, vt
+    assert "%016x" % total == gold["checksum"]
     with open(os.path.join(ROOT, "tests", "golden", "config5_checksum.json")) as f:
         assert "%016x" % total == json.load(f)["checksum"]
 
@@ -1055,6 +1083,8 @@ def test_full_size_config4_batch_normalize(eng, ora):
     want[ident] = torch.tensor([0] * 6 + [1] + [0] * 5, dtype=torch.int64, device="cuda")
     assert torch.equal(xy.view(torch.int64), want.view(torch.int64))
     assert int(inf.sum()) == len(ident) and bool(inf[ident].all())
+    g4 = _golden_block_sums("config4")                           # the oracle's batch_normalize over ALL 2^24 points, per block
+    assert _block_sums(xy) == g4["block_sums"] and [int(x) for x in inf.view(n >> 20, -1).sum(dim=1).tolist()] == g4["identities_per_block"]
     idx = np.arange(0, 4096)
     wxy, winf = ora.batch_normalize(host(jac)[idx], True)
     assert (host(xy)[idx] == wxy).all() and (host(inf)[idx] == winf).all()

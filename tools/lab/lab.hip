@@ -35,6 +35,18 @@ extern "C" int lab_multiply_vartime(const DeviceTables* tab, const u64* pts, con
     return (int)hipGetLastError();
 }
 extern "C" size_t lab_scratch_words_per_block() { return LaneScratch::WORDS_PER_BLOCK; }
+extern "C" int lab_multiply_vartime_pool(const DeviceTables* tab, const u64* pts, const u8* scalars, u64* out, u8* inf, size_t n, u64* scratch,
+                                         int blocks_per_cu, int proj, void* stream) {
+    const size_t per_round = (size_t)VtPool::SLOTS * BLOCK;
+    size_t want = (n + per_round - 1) / per_round, cap = (size_t)lab_num_cus() * blocks_per_cu;
+    const int grid = (int)(want < cap ? want : cap);
+    if (proj)
+        hipLaunchKernelGGL((k_multiply_vartime_pool<Proj, 0, 1>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, tab, pts, scalars, out, inf, n, scratch, VtPool::words(3));
+    else
+        hipLaunchKernelGGL((k_multiply_vartime_pool<MJac, 0, 2>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, tab, pts, scalars, out, inf, n, scratch, VtPool::words(4));
+    return (int)hipGetLastError();
+}
+extern "C" size_t lab_pool_words_per_block(int proj) { return VtPool::words(proj ? 3 : 4); }
 #endif
 
 #ifdef LAB_MANY
@@ -62,3 +74,11 @@ extern "C" void* lab_build_tables(const u64* gen_xy, const u64* shift_xy) {
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;
     return tab;
 }
+
+#ifdef LAB_COUNT
+extern "C" int lab_read_counters(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(lab_counters), 32) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lab_counters), z, 32) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
