@@ -140,6 +140,9 @@ CH_DEV u64 fp_halve(u64 a) { return (a >> 1) + ((a & 1ull) ? 0x7fffffff80000001u
 // Canonical representative in [0, p).               (src/fp.rs:125-127)
 CH_DEV u64 fp_canonical(u64 a) { return a >= FP_P ? a - FP_P : a; }
 CH_DEV bool fp_is_zero(u64 a) { return a == 0ull || a == FP_P; }
+// 0 exactly when a is 0 or p = (1, 0xffffffff): the high word is then minus the low word and the low word is 0 or 1.
+// Three full-rate instructions per limb and no compare, for OR-ing over several limbs (fp6_is_zero).
+CH_DEV u32 fp_nonzero_bits(u64 a) { return (hi32(a) + lo32(a)) | (lo32(a) >> 1); }
 
 // ---------------------------------------------------------------------------
 // Column accumulators.  A sum of 64x64 products is kept as three 64-bit columns

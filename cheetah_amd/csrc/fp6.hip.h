@@ -88,9 +88,9 @@ CH_DEV Fp6 fp6_mul_by_fp(const Fp6& a, u64 k) {  // src/fp6.rs:448-464
 // Branch-free on purpose (one OR over the canonical limbs): written as a chain of `&&` the compiler turned it into a
 // chain of divergent branches, i.e. control flow on the operand (tools/check_ct_isa.py).
 CH_DEV bool fp6_is_zero(const Fp6& a) {  // src/fp6.rs:362-369
-    u64 acc = 0;
+    u32 acc = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc |= fp_canonical(a.c[i]);
+    for (int i = 0; i < 6; i++) acc |= fp_nonzero_bits(a.c[i]);
     return acc == 0;
 }
 // subtle's conditional_select(a, b, choice) = choice ? b : a   (src/fp6.rs:247-258)

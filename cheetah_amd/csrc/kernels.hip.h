@@ -184,9 +184,9 @@ CH_DEV Fp6 curve_b() {  // B = u + 395, src/curve/mod.rs:42-49
 CH_DEV bool affine_is_identity_encoding(const Fp6& x, const Fp6& y) {  // branch-free, like fp6_is_zero
     u64 acc = fp_canonical(y.c[0]) ^ 1ull;
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc |= fp_canonical(x.c[i]);
+    for (int i = 0; i < 6; i++) acc |= fp_nonzero_bits(x.c[i]);
 #pragma unroll
-    for (int i = 1; i < 6; i++) acc |= fp_canonical(y.c[i]);
+    for (int i = 1; i < 6; i++) acc |= fp_nonzero_bits(y.c[i]);
     return acc == 0;
 }
 

@@ -23,6 +23,10 @@ k = eng.synth_scalars(5, n, 0)
 for _ in range(2):
     out, oinf = eng.multiply_batch(pts, k, AFFINE, AFFINE)         # k_multiply_ct<MJac,0,0>
 vt, vinf = eng.multiply_vartime_batch(pts, k, AFFINE, AFFINE)  # k_multiply_vartime<MJac,0,0>
+from cheetah_amd import PROJECTIVE  # noqa: E402
+pr, pinf = eng.multiply_vartime_batch(pts, k, AFFINE, PROJECTIVE)   # k_multiply_vartime_pool<Proj,0,1>
+jv, jvinf = eng.multiply_vartime_batch(pts, k, AFFINE, JACOBIAN)    # k_multiply_vartime_pool<MJac,0,2>
+mm, minf = eng.multiply_many_batch(pts, k, 2, AFFINE, AFFINE)      # k_multiply_many_ct<MJac,0,0>
 jac, jinf = eng.multiply_batch(pts, k, AFFINE, JACOBIAN)
 nb = min(1 << 24, n * 16)
 big = jac.repeat(nb // n, 1).contiguous()
