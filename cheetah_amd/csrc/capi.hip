@@ -938,12 +938,12 @@ static size_t form_limbs(int form) { return form == CHEETAH_AFFINE ? 12 : 18; }
 // caller-supplied base (tables may hold identities).
 template <bool GENERIC>
 static int32_t fixed_base_impl(cheetah_ctx* ctx, const u64* comb, const u64* wide, const u8* scalars32, u64* out, u8* inf, size_t n,
-                               int out_form) {
+                               int out_form, bool reference_comb = false) {
     SET_DEVICE(ctx);
     if (!aligned8(scalars32) || !aligned8(out)) return fail(ctx, CHEETAH_ERR_INVALID, "device pointers must be 8-byte aligned");
     if (out_form != CHEETAH_JACOBIAN && !inf)
         return fail(ctx, CHEETAH_ERR_INVALID, "inf must not be NULL for BasePointTable forms: it carries the out-of-range flag 0xFF");
-    if (out_form == CHEETAH_AFFINE) {  // affine results: the widened comb (one 1 024-thread workgroup per CU)
+    if (out_form == CHEETAH_AFFINE && !(GENERIC && reference_comb)) {  // affine results: the widened comb (one 1 024-thread workgroup per CU)
         size_t want = (n + WIDE_BLOCK - 1) / WIDE_BLOCK;
         const size_t cus_w = (size_t)(ctx->num_cus - ctx->reserved_cus);
         int grid_w = (int)(want < cus_w ? want : cus_w);
@@ -961,8 +961,14 @@ static int32_t fixed_base_impl(cheetah_ctx* ctx, const u64* comb, const u64* wid
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u8* sc_o = scalars32 + off * 32;
-        u64* out_o = out + off * 18;
+        u64* out_o = out + off * (out_form == CHEETAH_AFFINE ? 12 : 18);
         u8* inf_o = inf ? inf + off : nullptr;
+        if constexpr (GENERIC) {
+            if (out_form == CHEETAH_AFFINE) {  // an off-curve base: the reference's comb, normalised
+                hipLaunchKernelGGL((k_mul_by_generator<0, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, comb, sc_o, out_o, inf_o, cnt);
+                continue;
+            }
+        }
         if (out_form == CHEETAH_PROJECTIVE)
             hipLaunchKernelGGL((k_mul_by_generator<1, GENERIC>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables, comb, sc_o, out_o, inf_o, cnt);
         else if (!GENERIC)
@@ -1011,6 +1017,10 @@ extern "C" int32_t cheetah_mul_by_generator_batch(cheetah_ctx* ctx, const uint8_
 struct cheetah_basepoint_table {
     cheetah_ctx* ctx = nullptr;
     std::vector<u64*> comb, wide;  // one copy per shard of the context
+    // A base that is NOT on the curve (an unchecked decoding can produce one): the reference's comb still returns a
+    // definite value for it, but the widened comb -- another schedule over other multiples -- returns another, so AFFINE
+    // results then come from the reference's comb and a normalisation (k_mul_by_generator<0, GENERIC>).
+    bool on_curve = true;
 };
 constexpr size_t COMB_WORDS = 32 * 8 * 12, WIDE_WORDS = (size_t)WIDE_WINDOWS * WIDE_ENTRIES * 12;
 
@@ -1057,7 +1067,14 @@ extern "C" int32_t cheetah_basepoint_table_create(cheetah_ctx* ctx, const uint64
                     hipLaunchKernelGGL((k_build_comb_table<1>), dim3(1), dim3(64), 0, c->stream, t->comb[i], pt);
                     hipLaunchKernelGGL((k_build_wide_table<1>), dim3(WIDE_WINDOWS), dim3(64), 0, c->stream, t->wide[i], pt);
                 }
+                u8* flag = reinterpret_cast<u8*>(pt + 20);
+                if (in_form == CHEETAH_AFFINE) hipLaunchKernelGGL((k_is_on_curve<0>), dim3(1), dim3(BLOCK), 0, c->stream, pt, flag, (size_t)1);
+                else hipLaunchKernelGGL((k_is_on_curve<1>), dim3(1), dim3(BLOCK), 0, c->stream, pt, flag, (size_t)1);
                 e = hipGetLastError();
+                u8 on = 1;
+                if (e == hipSuccess) e = hipMemcpyAsync(&on, flag, 1, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess && !on) t->on_curve = false;
             }
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `point` is the caller's: done with it on return
         }
@@ -1087,7 +1104,7 @@ static int32_t table_multiply_op(cheetah_ctx* ctx, bool host, const cheetah_base
     op.io = {in_(scalars32, 32), out_(out, form_limbs(out_form) * 8), out_(inf, 1, host && out_form != CHEETAH_AFFINE, true)};
     op.launch = [out_form, t](cheetah_ctx* c, void* const* d, size_t cnt) {
         return fixed_base_impl<true>(c, t->comb[c->shard_index], t->wide[c->shard_index], at<u8>(d, 0), at<u64>(d, 1), at<u8>(d, 2), cnt,
-                                     out_form);
+                                     out_form, !t->on_curve);
     };
     return run_op(ctx, host, op);
 }

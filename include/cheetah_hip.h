@@ -179,7 +179,9 @@ int32_t cheetah_mul_by_generator_batch_dev(cheetah_ctx *ctx, const uint8_t *scal
  *                                  out[i] = scalars[i] * P = BasePointTable::multiply        src/lookup.rs:189-206
  *                                  (multiply_vartime, :216-233, is the same body -- SURVEY Q2 -- hence the same call).
  *                                  out_form PROJECTIVE: the reference's comb step for step, its own (X:Y:Z);
- *                                  AFFINE: the affine point by the widened comb.  Range rule and inf as for
+ *                                  AFFINE: the affine point by the widened comb (a base that is NOT on the curve,
+ *                                  which create() detects, takes the reference's comb and a normalisation instead,
+ *                                  so that the value stays the reference's).  Range rule and inf as for
  *                                  cheetah_mul_by_generator_batch.  With P = G this is `&BASEPOINT_TABLE * &Scalar`
  *                                  (the relation the reference tests, src/curve/projective.rs:1328-1351).
  * cheetah_basepoint_table_read     the 256 affine entries, table-major (tests; get_basepoint() is entry 0, :176-178)

@@ -236,7 +236,13 @@ def test_basepoint_table_create_and_multiply_random_bases(eng, ora):
     k[1, 0] = 1
     k[2] = np.frombuffer(((1 << 255) - 1).to_bytes(32, "little"), np.uint8)
     k[3] = np.frombuffer((synth.Q - 1).to_bytes(32, "little"), np.uint8)
-    for base, form in [(bases[0], AFFINE), (bases[1], AFFINE), (proj_base, PROJECTIVE), (IDENT, AFFINE)]:
+    off_aff = bases[2].copy()
+    off_aff[0] ^= np.uint64(9)                       # NOT on the curve: both forms must still be the reference comb's values
+    off_proj = proj_base.copy()
+    off_proj[7] = (int(off_proj[7]) + 3) % P
+    assert ora.is_on_curve_batch(off_aff[None, :], 0)[0] == 0 and ora.is_on_curve_batch(off_proj[None, :], 1)[0] == 0
+    for base, form in [(bases[0], AFFINE), (bases[1], AFFINE), (proj_base, PROJECTIVE), (IDENT, AFFINE), (off_aff, AFFINE),
+                       (off_proj, PROJECTIVE)]:
         t = eng.basepoint_table(base, form)
         wt = ora.basepoint_table_create(base, form)
         assert (t.read() == wt[0]).all()
