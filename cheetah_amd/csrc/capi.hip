@@ -1131,6 +1131,7 @@ extern "C" int32_t cheetah_basepoint_table_read(cheetah_ctx* ctx, const cheetah_
 
 // arena == nullptr: the context's own scratch; otherwise a caller-chosen arena that holds
 // max_blocks workgroups' tables, and the grids are capped to it (the kernels grid-stride over the rest).
+constexpr size_t POOL_ROUNDS_FACTOR = 8;
 template <bool VARTIME>
 static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, const u8* scalars32, u64* out, u8* inf, size_t n,
                              int out_form, u64* arena = nullptr, int max_blocks = 0) {
@@ -1160,7 +1161,10 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
     // The workgroups are persistent within a launch and fill every CU, so a kernel on another stream (the RCCL
     // all-gather of the previous chunk) can only get CU slots at a launch boundary: bounding the launch bounds its wait.
     const size_t in_w = form_limbs(in_form), out_w = form_limbs(out_form);
-    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds * (pooled ? VtPool::SLOTS : 1);
+    // The pooled kernel's rounds end wave by wave (each wave's NAFs have their own length), so a launch boundary costs it
+    // more than it costs the lock-step ladders: measured at 2^22, projective representative, 20.6 M/s at 2 rounds per launch,
+    // 21.7 at 16 (profiles/r03_ladder_timings.txt).  Its launches therefore cover POOL_ROUNDS_FACTOR times as many rounds.
+    const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds * (pooled ? VtPool::SLOTS * POOL_ROUNDS_FACTOR : 1);
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u64* pts_o = pts + off * in_w;
@@ -1857,7 +1861,7 @@ extern "C" int32_t cheetah_multiply_units_per_launch(cheetah_ctx* ctx, size_t n,
     if (!units) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
     const bool pooled = vartime && out_form != CHEETAH_AFFINE;
     const size_t slots = pooled ? VtPool::SLOTS : 1;
-    const size_t per_launch = (size_t)lane_grid(ctx, ((n ? n : 1) + slots - 1) / slots, pooled ? CH_VT_POOL_WAVES : CH_CT_WAVES) * BLOCK * slots * ctx->launch_rounds;
+    const size_t per_launch = (size_t)lane_grid(ctx, ((n ? n : 1) + slots - 1) / slots, pooled ? CH_VT_POOL_WAVES : CH_CT_WAVES) * BLOCK * slots * ctx->launch_rounds * (pooled ? POOL_ROUNDS_FACTOR : 1);
     *units = n < per_launch ? n : per_launch;
     return CHEETAH_OK;
 }

@@ -6,6 +6,8 @@ import torch
 from cheetah_amd import AFFINE, JACOBIAN, PROJECTIVE, Engine
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 eng = Engine(0)
+if len(sys.argv) > 2:
+    eng.set_launch_rounds(int(sys.argv[2]))   # rounds of the resident grid per launch (library default 2)
 n = 1 << lg
 r = eng.synth_scalars(5, n, 1 << 26)
 k = eng.synth_scalars(5, n, 0)
@@ -25,5 +27,6 @@ a = timed("multiply ct affine->affine (MJac)", lambda: eng.multiply_batch(pts, k
 timed("multiply ct affine->projective (Proj)", lambda: eng.multiply_batch(pts, k, AFFINE, PROJECTIVE))
 b = timed("multiply_vartime affine->affine (MJac)", lambda: eng.multiply_vartime_batch(pts, k, AFFINE, AFFINE))
 timed("multiply_vartime affine->projective (Proj)", lambda: eng.multiply_vartime_batch(pts, k, AFFINE, PROJECTIVE))
+timed("multiply_vartime affine->jacobian (MJac)", lambda: eng.multiply_vartime_batch(pts, k, AFFINE, JACOBIAN))
 assert torch.equal(a[0].view(torch.int64), b[0].view(torch.int64))
 eng.close()
