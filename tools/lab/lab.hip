@@ -100,7 +100,7 @@ template <bool DIRECT>
 __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_lab_multiply_w5(const DeviceTables* __restrict__ tab, const u64* __restrict__ consts,
                                                                        const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                                        u64* __restrict__ out, u8* __restrict__ inf, size_t n,
-                                                                       u64* __restrict__ scratch) {
+                                                                       u64* __restrict__ scratch, int n_entries /* 16, a run-time value as in the product */) {
     __shared__ i8 s_digits[52 * BLOCK];
     const int t = threadIdx.x;
     u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
@@ -118,13 +118,49 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_lab_multiply_w5(const De
         __syncthreads();
         recode_radix32(k, s_digits, t);
         __syncthreads();
-        const u32 ident = build_lookup_table<0, DIRECT>(pts, ii, 16, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_lookup_table<0, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
         int d = s_digits[51 * BLOCK + t];
-        MJac acc = Ladder<MJac>::add(shift32, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, 16, ident, d, t));
+        MJac acc = Ladder<MJac>::add(shift32, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
         for (int j = 50; j >= 0; j--) {
             acc = Ladder<MJac>::dbls_then_add(acc, 5);
             d = s_digits[j * BLOCK + t];
-            acc = Ladder<MJac>::add_after_dbl(acc, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, 16, ident, d, t));
+            acc = Ladder<MJac>::add_after_dbl(acc, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
+        }
+        acc = Ladder<MJac>::add_last(acc, mshift);
+        if (active) emit_point<0>(out, inf, i, acc);
+    }
+}
+// Upper bound of what a co-Z step (the window's last doubling and its addition sharing z, 11 M + 7 S per
+// window instead of 11 M + 9 S) could gain, WITHOUT building it: the product's radix-16 ladder with the two squarings that
+// rebuild z^4 after every addition simply left out.  The results are wrong (z4 is stale), the instruction stream is the
+// product's minus 2 S per window and nothing added for the odd-digit recoding, the table of odd multiples or the closing
+// correction a real co-Z ladder needs; the kernel is constant time, so its duration does not depend on the values.
+__global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_lab_multiply_w4_minus2s(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
+                                                                               const u8* __restrict__ scalars, u64* __restrict__ out,
+                                                                               u8* __restrict__ inf, size_t n, u64* __restrict__ scratch, int n_entries /* 8 */) {
+    __shared__ i8 s_digits[64 * BLOCK];
+    const int t = threadIdx.x;
+    u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
+    u64* s_z = s_tab + (size_t)16 * 12 * BLOCK;
+    u64* s_prefix = s_z + (size_t)16 * 6 * BLOCK;
+    const Affine mshift = load_affine(tab->minus_shift_256);
+    const size_t nround = (n + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i = round * BLOCK + t;
+        const bool active = i < n;
+        const size_t ii = active ? i : n - 1;
+        u64 k[4];
+        load_scalar(scalars, ii, k);
+        __syncthreads();
+        recode_radix16(k, s_digits, t);
+        __syncthreads();
+        const u32 ident = build_lookup_table<0, false>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
+        int d = s_digits[63 * BLOCK + t];
+        MJac acc = Ladder<MJac>::add(Ladder<MJac>::shift16(tab), scan_lookup(s_tab, n_entries, ident, d, t));
+        for (int j = 62; j >= 0; j--) {
+            acc = Ladder<MJac>::dbls_then_add(acc, 4);
+            d = s_digits[j * BLOCK + t];
+            acc = Ladder<MJac>::add_last(acc, scan_lookup(s_tab, n_entries, ident, d, t));  // no z^4: 2 S fewer, wrong on purpose
         }
         acc = Ladder<MJac>::add_last(acc, mshift);
         if (active) emit_point<0>(out, inf, i, acc);
@@ -140,8 +176,9 @@ extern "C" int lab_multiply_w(int w, int direct, const DeviceTables* tab, const 
     size_t want = (n + BLOCK - 1) / BLOCK, cap = (size_t)lab_num_cus() * CH_CT_WAVES;
     const int grid = (int)(want < cap ? want : cap);
     hipStream_t st = (hipStream_t)stream;
-    if (w == 5 && direct) hipLaunchKernelGGL((k_lab_multiply_w5<true>), dim3(grid), dim3(BLOCK), 0, st, tab, consts, pts, scalars, out, inf, n, scratch);
-    else if (w == 5) hipLaunchKernelGGL((k_lab_multiply_w5<false>), dim3(grid), dim3(BLOCK), 0, st, tab, consts, pts, scalars, out, inf, n, scratch);
+    if (w == 40) hipLaunchKernelGGL(k_lab_multiply_w4_minus2s, dim3(grid), dim3(BLOCK), 0, st, tab, pts, scalars, out, inf, n, scratch, 8);
+    else if (w == 5 && direct) hipLaunchKernelGGL((k_lab_multiply_w5<true>), dim3(grid), dim3(BLOCK), 0, st, tab, consts, pts, scalars, out, inf, n, scratch, 16);
+    else if (w == 5) hipLaunchKernelGGL((k_lab_multiply_w5<false>), dim3(grid), dim3(BLOCK), 0, st, tab, consts, pts, scalars, out, inf, n, scratch, 16);
     else if (direct) hipLaunchKernelGGL((k_multiply_ct<MJac, 0, 0, true>), dim3(grid), dim3(BLOCK), 0, st, tab, pts, scalars, out, inf, n, scratch);
     else hipLaunchKernelGGL((k_multiply_ct<MJac, 0, 0, false>), dim3(grid), dim3(BLOCK), 0, st, tab, pts, scalars, out, inf, n, scratch);
     return (int)hipGetLastError();

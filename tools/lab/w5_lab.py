@@ -47,4 +47,12 @@ for direct in (0, 1):
                                                 scratch.data_ptr(), st))
         ok = torch.equal(out, want.view(torch.int64)) and torch.equal(inf, winf)
         print("%-8s w=%d  2^%d: %9.3f ms  %7.3f M/s  equal=%s" % ("indexed" if direct else "ct scan", w, lg, ms, n / ms / 1e3, ok), flush=True)
+# the co-Z upper bound: the product's ladder minus 2 S per window (results wrong on purpose, see lab.hip)
+for rep in range(2):
+    out = torch.full((n, 12), -1, dtype=torch.int64, device="cuda")
+    inf = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = L.timed(lambda: lib.lab_multiply_w(40, 0, tab, consts.data_ptr(), pts.data_ptr(), k.data_ptr(), out.data_ptr(), inf.data_ptr(), n,
+                                            scratch.data_ptr(), st))
+    print("ct scan  w=4 minus 2 S per window (co-Z upper bound, not a multiplication)  2^%d: %9.3f ms  %7.3f M/s" % (lg, ms, n / ms / 1e3), flush=True)
 eng.close()
