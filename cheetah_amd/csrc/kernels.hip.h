@@ -1232,19 +1232,31 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
 // is followed by four zeros).  The loop enforces that bound and flags what is unfinished (zero limbs, inf = 0xFE)
 // instead of spinning.
 //   phase policy (the model in tools/naf_pool_sim.py, statement for statement):
-//     additions if >= 64 items are parked at a non-zero digit, else doublings if >= 64 can double, else the larger group;
+//     additions (each with the run of doublings that follows it in the item's sequence, see CH_VT_RUN) if >= 64 items
+//     are parked at a non-zero digit, else single doublings if >= 64 can double, else the larger group;
 //     among the candidates those at or above the candidates' mean position first (the laggards), slots and lanes in an
 //     order that rotates with the phase number.
 #ifndef CH_VT_SLOTS
 #define CH_VT_SLOTS 2
 #endif
 // Measured (tools/lab/vt_lab.py, 2^22, affine in; parked = k_multiply_vartime): projective representative 18.5 M/s parked,
-// pooled 21.7 at 3 waves per SIMD and 2 slots (20.8 at 4 waves, 20.6 with 3 slots, 20.8 with the accumulators SoA like the
-// tables, 20.9 with the doublings through calls); Jacobian representative 23.1 parked, pooled 24.9 (14.3 at 4 waves, where
-// the loop spills).  With no accumulator traffic at all the pooled schedule would reach 24.8 / 30.5: its loads and its
-// stores each cost ~ 6 % (SQ_INSTS_VALU + 9 % per phase for addresses, packing and the scheduling itself).
+// pooled with one step per phase 21.7-21.9 at 3 waves per SIMD and 2 slots (20.8 at 4 waves, 20.6 with 3 slots, 20.8 with
+// the accumulators SoA like the tables, 20.9 with the doublings through calls); Jacobian representative 23.1 parked, pooled
+// 24.7-24.9.  With no accumulator traffic at all that schedule would reach 24.8 / 30.5: its loads and its stores each cost
+// ~ 6 % (SQ_INSTS_VALU + 9 % per phase for addresses, packing and the scheduling itself).  Hence the fused runs
+// (CH_VT_RUN): an addition phase goes on with the doublings that follow it -- 24.1 / 29.4 M/s with runs of 5 that
+// shorten to 4 below position 60 (23.7 / 28.7 with runs of 4 throughout, 23.0 / 28.3 with 5 throughout, 22.8 / 27.5 with
+// 3 slots; 4 waves per SIMD the same as 3).
 #ifndef CH_VT_POOL_WAVES
 #define CH_VT_POOL_WAVES 3
+#endif
+// doublings fused behind an addition in one phase (0: none, the first form of this kernel), and the mean position of a
+// phase's candidates below which one fewer is fused
+#ifndef CH_VT_RUN
+#define CH_VT_RUN 5
+#endif
+#ifndef CH_VT_RUN_SWITCH
+#define CH_VT_RUN_SWITCH 60
 #endif
 #ifdef LAB_COUNT
 __device__ unsigned long long lab_counters[4];  // tools/lab only: doubling phases, addition phases, lanes used in each
@@ -1392,11 +1404,19 @@ __global__ void __launch_bounds__(BLOCK, CH_VT_POOL_WAVES) k_multiply_vartime_po
                 atomicAdd(&lab_counters[add ? 3 : 2], (unsigned long long)take);
             }
 #endif
+            // an addition phase goes on with the doublings that follow the addition in every item's sequence: a non-zero
+            // width-5 NAF digit is followed by four zeros, so doublings 1..4 meet no digit and the fifth is the first that
+            // can.  One load and one store of the accumulator for up to six steps; five while the candidates are still far
+            // from the end (mean position > CH_VT_RUN_SWITCH), four after, which keeps the items in step at the tail
+            // (tools/naf_pool_sim.py: 96 phases per 64 items instead of 300, 98.7 % of the lane-steps used).
+            const int run = CH_VT_RUN == 0 ? 0 : (sum > CH_VT_RUN_SWITCH * cnt ? CH_VT_RUN : CH_VT_RUN - 1);
             if (lane < take) {
                 const int code = s_list[wbase + lane];
                 const int s = code >> 6, tt = wbase + (code & 63);
                 u64* st = state0 + (size_t)s * NF * 6 * BLOCK;
                 ACC acc = AccIO<ACC>::load(st, tt);
+                const int p = s_pos[s * BLOCK + tt];  // the next position to double at
+                int ndbl = 1;
                 if (add) {
                     const int pd = s_pd[s * BLOCK + tt];
                     const int e = (pd < 0 ? -pd : pd) >> 1;  // NafLookupTable::get_point(x) = table[x / 2]
@@ -1406,13 +1426,16 @@ __global__ void __launch_bounds__(BLOCK, CH_VT_POOL_WAVES) k_multiply_vartime_po
                     q.y = sc_load(tb, e, 6, tt, 12);
                     q.inf = (s_ident[s * BLOCK + tt] >> e) & 1;
                     acc = Ladder<ACC>::add(acc, affine_cond_neg(q, pd < 0));
-                    s_pd[s * BLOCK + tt] = 0;
-                } else {
-                    acc = Ladder<ACC>::dbl_inl(acc);
-                    const int p = s_pos[s * BLOCK + tt];
-                    s_pd[s * BLOCK + tt] = (i8)naf4_digit(s_naf + (size_t)s * 64 * BLOCK, p, tt);
-                    s_pos[s * BLOCK + tt] = (short)(p - 1);
+                    ndbl = p + 1 < run ? p + 1 : run;  // an item close to its end has fewer doublings left
                 }
+#pragma unroll 1
+                for (int j = 0; j < (CH_VT_RUN > 1 ? CH_VT_RUN : 1); j++) {  // ONE doubling body for both kinds of phase
+                    if (j >= ndbl) break;
+                    acc = Ladder<ACC>::dbl_inl(acc);
+                }
+                // the digit the last doubling of the run arrives at (the ones before it are zeros by construction)
+                s_pd[s * BLOCK + tt] = ndbl > 0 ? (i8)naf4_digit(s_naf + (size_t)s * 64 * BLOCK, p - ndbl + 1, tt) : (i8)0;
+                s_pos[s * BLOCK + tt] = (short)(p - ndbl);
                 AccIO<ACC>::store(st, acc, tt);
             }
             __threadfence_block();  // the accumulators just stored are read by other lanes of this wave in a later phase

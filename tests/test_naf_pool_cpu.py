@@ -1,7 +1,8 @@
 """The wave-pool scheduler of k_multiply_vartime_pool (cheetah_amd/csrc/kernels.hip.h), modelled on the CPU
 (tools/naf_pool_sim.py: the kernel's phase policy statement for statement) and run on seeded width-5 NAFs
-(src/scalar.rs:585-643): every item takes exactly its 256 doublings and one addition per non-zero digit, the loop
-terminates far inside the kernel's hard phase bound, and the lane utilisation is what DESIGN.md quotes."""
+(src/scalar.rs:585-643): every item takes exactly its 256 doublings and one addition per non-zero digit (an addition phase going on
+with the up-to-five doublings that follow it), the loop terminates far inside the kernel's hard phase bound, and the
+lane utilisation is what DESIGN.md quotes."""
 import os
 import random
 import sys
@@ -43,4 +44,21 @@ def test_two_slots_keep_the_lanes_busy():
     r2 = sim.simulate(2, 4, seed=11)
     assert r2["lane_utilisation"] > 0.96 and r2["efficiency"] > 0.96
     assert r1["lane_utilisation"] < 0.85                          # one item per lane: what the pool is for
-    assert abs(r2["doubling_phases_per_wave"] / 2 - 256) < 6     # ~ 257 doubling phases per 64 items
+    # the doublings that follow an addition ride in its phase: ~ 100 phases per 64 items (one load and one store of the
+    # accumulator each) instead of the ~ 300 of one step per phase, at nearly the same lane utilisation
+    phases = (r2["doubling_phases_per_wave"] + r2["addition_phases_per_wave"]) / 2
+    assert 80 < phases < 115
+    r0 = sim.simulate(2, 4, seed=11, run=0)
+    assert abs(r0["doubling_phases_per_wave"] / 2 - 256) < 6 and r0["lane_utilisation"] > 0.98
+    assert r2["time_per_64_items"] < 1.04 * r0["time_per_64_items"]
+
+
+def test_fused_runs_never_skip_a_digit():
+    """run_wave asserts, for every doubling of a fused run but the last, that the digit it arrives at is zero: with
+    runs of 5 that is the width-5 NAF's guarantee of four zeros after a non-zero digit -- a run of 6 must trip it."""
+    import pytest
+    rng = random.Random(13)
+    nafs = [[sim.wnaf5(rng.randrange(sim.Q)) for _ in range(64)] for _ in range(2)]
+    sim.run_wave(nafs, 2, run=5)
+    with pytest.raises(AssertionError):
+        sim.run_wave(nafs, 2, run=7)
