@@ -58,6 +58,7 @@ SIGNATURES = {
     "cheetah_fp6_exp_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_fp6_exp_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_random_points_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _sz, _i]),
+    "cheetah_random_points": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _sz, _i]),
     "cheetah_fp6_mul_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),
     "cheetah_fp6_square_batch": (C.c_int32, [_vp, _vp, _vp, _sz]),
     "cheetah_fp6_invert_batch": (C.c_int32, [_vp, _vp, _vp, _vp, _sz]),

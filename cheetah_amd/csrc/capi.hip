@@ -1844,6 +1844,37 @@ extern "C" int32_t cheetah_random_points_dev(cheetah_ctx* ctx, uint64_t seed, ui
     return CHEETAH_OK;
 }
 
+// The same stream into HOST arrays (what a host-side `random()` replacement calls): generated on the first device in the
+// same sub-batches and copied out; element i of a stream does not depend on how the stream is cut.
+extern "C" int32_t cheetah_random_points(cheetah_ctx* ctx, uint64_t seed, uint64_t start, uint64_t* out, uint8_t* inf, size_t n,
+                                         int out_form) {
+    if (!ctx) return CHEETAH_ERR_INVALID;
+    if (int32_t rc = check_forms(ctx, CHEETAH_AFFINE, out_form)) return rc;
+    SET_DEVICE(ctx);
+    if (n == 0) return CHEETAH_OK;
+    if (!out || (out_form == CHEETAH_AFFINE && !inf)) return fail(ctx, CHEETAH_ERR_INVALID, "null pointer");
+    constexpr size_t SUB = (size_t)1 << 19;
+    const size_t cap = n < SUB ? n : SUB, out_w = form_limbs(out_form);
+    u64* d_out = nullptr;
+    u8* d_inf = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), cap * out_w * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_inf), cap);
+    int32_t rc = CHEETAH_OK;
+    for (size_t off = 0; off < n && e == hipSuccess && rc == CHEETAH_OK; off += SUB) {
+        const size_t cnt = n - off < SUB ? n - off : SUB;
+        rc = cheetah_random_points_dev(ctx, seed, start + off, d_out, d_inf, cnt, out_form);
+        if (rc != CHEETAH_OK) break;
+        e = hipMemcpyAsync(out + off * out_w, d_out, cnt * out_w * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && inf) e = hipMemcpyAsync(inf + off, d_inf, cnt, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (d_inf) (void)hipFree(d_inf);
+    if (rc != CHEETAH_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? CHEETAH_ERR_NOMEM : CHEETAH_ERR_HIP, hipGetErrorString(e));
+    return CHEETAH_OK;
+}
+
 // ---------------------------------------------------------- diagnostics -----
 
 extern "C" int32_t cheetah_debug_op_dev(cheetah_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {

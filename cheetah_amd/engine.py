@@ -208,10 +208,15 @@ class Engine:
         self._check(self._lib.cheetah_fp6_exp_batch(self._h, x.ctypes.data, C.addressof(pw), out.ctypes.data, len(x)))
         return out
 
-    def random_points(self, seed, n, start=0, out_form=AFFINE):
+    def random_points(self, seed, n, start=0, out_form=AFFINE, host=False):
         """n seeded points of the prime-order subgroup shaped like {Affine,Projective,Jacobian}Point::random
-        (src/curve/projective.rs:228-248): x drawn, y = +-sqrt(x^3 + x + B), cofactor cleared.  Device tensors (out, inf)."""
+        (src/curve/projective.rs:228-248): x drawn, y = +-sqrt(x^3 + x + B), cofactor cleared.  Device tensors (out, inf),
+        or numpy arrays with host=True (the same stream through the host-pointer entry point)."""
         w = self._out_width(out_form)
+        if host:
+            out, inf = np.empty((n, w), np.uint64), np.empty(n, np.uint8)
+            self._check(self._lib.cheetah_random_points(self._h, int(seed), int(start), out.ctypes.data, inf.ctypes.data, n, out_form))
+            return out, inf
         out, inf = self._empty((n, w), torch.uint64), self._empty((n,), torch.uint8)
         self._use_torch_stream()
         self._check(self._lib.cheetah_random_points_dev(self._h, int(seed), int(start), out.data_ptr(), inf.data_ptr(), n, out_form))

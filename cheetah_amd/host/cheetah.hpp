@@ -104,6 +104,28 @@ inline std::vector<Fp6> fp6_sqrt_batch(const Context& ctx, const std::vector<Fp6
     return out;
 }
 
+// out[i] = a[i]^power            Fp6::exp / exp_vartime, src/fp6.rs:1053-1086 (power: six little-endian u64 words)
+inline std::vector<Fp6> fp6_exp_batch(const Context& ctx, const std::vector<Fp6>& a, const std::array<uint64_t, 6>& power) {
+    std::vector<Fp6> out(a.size());
+    ctx.check(cheetah_fp6_exp_batch(ctx.get(), u64p(a.data()), power.data(), u64p(out.data()), a.size()));
+    return out;
+}
+
+// ---- Fp (values are any u64, results canonical; src/fp.rs) ---------------------------
+// out[i] = sqrt(a[i]), is_some[i]  Fp::sqrt -> CtOption, src/fp.rs:199-229
+inline std::vector<uint64_t> fp_sqrt_batch(const Context& ctx, const std::vector<uint64_t>& a, std::vector<uint8_t>& is_some) {
+    std::vector<uint64_t> out(a.size());
+    is_some.assign(a.size(), 0);
+    ctx.check(cheetah_fp_op_batch(ctx.get(), CHEETAH_FP_SQRT, a.data(), nullptr, 0, out.data(), is_some.data(), a.size()));
+    return out;
+}
+// out[i] = a[i]^power              Fp::exp / exp_vartime, src/fp.rs:304-333
+inline std::vector<uint64_t> fp_exp_batch(const Context& ctx, const std::vector<uint64_t>& a, uint64_t power) {
+    std::vector<uint64_t> out(a.size());
+    ctx.check(cheetah_fp_op_batch(ctx.get(), CHEETAH_FP_EXP, a.data(), nullptr, power, out.data(), nullptr, a.size()));
+    return out;
+}
+
 // ---- batch_normalize ----------------------------------------------------------
 // ProjectivePoint::batch_normalize(p, q), src/curve/projective.rs:897-930
 inline void batch_normalize(const Context& ctx, const std::vector<ProjectivePoint>& p, std::vector<AffinePoint>& q,
@@ -264,6 +286,22 @@ inline std::vector<ProjectivePoint> clear_cofactor_batch(const Context& ctx, con
     std::vector<ProjectivePoint> out(p.size());
     ctx.check(cheetah_clear_cofactor_batch(ctx.get(), u64p(p.data()), CHEETAH_PROJECTIVE, u64p(out.data()), nullptr, p.size(),
                                            CHEETAH_PROJECTIVE));
+    return out;
+}
+
+// n points shaped like ProjectivePoint::random (src/curve/projective.rs:228-248) / AffinePoint::random
+// (src/curve/affine.rs:243-245), from a seed instead of a caller's rng: element i of stream `seed` is a function of
+// (seed, start + i) only (include/cheetah_hip.h).
+inline std::vector<ProjectivePoint> random_projective_batch(const Context& ctx, uint64_t seed, size_t n, uint64_t start = 0) {
+    std::vector<ProjectivePoint> out(n);
+    ctx.check(cheetah_random_points(ctx.get(), seed, start, u64p(out.data()), nullptr, n, CHEETAH_PROJECTIVE));
+    return out;
+}
+inline std::vector<AffinePoint> random_affine_batch(const Context& ctx, uint64_t seed, size_t n, std::vector<uint8_t>& infinity,
+                                                    uint64_t start = 0) {
+    std::vector<AffinePoint> out(n);
+    infinity.assign(n, 0);
+    ctx.check(cheetah_random_points(ctx.get(), seed, start, u64p(out.data()), infinity.data(), n, CHEETAH_AFFINE));
     return out;
 }
 

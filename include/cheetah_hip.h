@@ -402,8 +402,10 @@ int32_t cheetah_synth_scalars_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t star
  * a = 0, 1, ... takes x = (d(i, 7a) % p, ..., d(i, 7a + 5) % p) (Fp6::random) and flip_sign = low 32 bits of d(i, 7a + 6) odd;
  * the first attempt whose x^3 + x + B is a square gives (x, y or -y), y = Fp6::sqrt(...); then clear_cofactor.  The
  * reference retries on the identity; here that element (probability ~ 2^-255), or one with no square among its 36
- * attempts (2^-36), is returned as the identity (inf = 1).  Device pointers, 16-byte aligned; inf required for AFFINE. */
+ * attempts (2^-36), is returned as the identity (inf = 1).  _dev: device pointers, 16-byte aligned; the other form
+ * fills HOST arrays with the same stream (blocking).  inf is required for AFFINE and may be NULL otherwise. */
 int32_t cheetah_random_points_dev(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint64_t *out, uint8_t *inf, size_t n, int out_form);
+int32_t cheetah_random_points(cheetah_ctx *ctx, uint64_t seed, uint64_t start, uint64_t *out, uint8_t *inf, size_t n, int out_form);
 
 /* ---- diagnostics -----------------------------------------------------------
  * Unit-level parity hook: applies ONE device function to n operand tuples.

@@ -186,6 +186,17 @@ impl Fp6 {
     }
 }
 
+impl Fp6 {
+    /// out[i] = a[i]^power, power as six little-endian u64 words  (Fp6::exp / exp_vartime).
+    pub fn exp_batch(ctx: &mut GpuContext, a: &[Fp6], power: &[u64; 6]) -> Result<Vec<Fp6>, BatchError> {
+        let fa = fp6_limbs(a);
+        let mut out = vec![[0u64; 6]; a.len()];
+        let rc = unsafe { sys::cheetah_fp6_exp_batch(ctx.0, fa.as_ptr().cast(), power.as_ptr(), out.as_mut_ptr().cast(), a.len()) };
+        ctx.check(rc)?;
+        Ok(fp6_from(out))
+    }
+}
+
 // ---- variable base ----------------------------------------------------------------------------------------
 
 fn multiply_affine(ctx: &mut GpuContext, p: &[AffinePoint], k: &[Scalar], vartime: bool) -> Result<Vec<AffinePoint>, BatchError> {
@@ -236,6 +247,52 @@ impl ProjectivePoint {
         let rc = unsafe {
             sys::cheetah_multiply_batch(ctx.0, pl.as_ptr().cast(), sys::CHEETAH_PROJECTIVE, kb.as_ptr().cast(), out.as_mut_ptr().cast(),
                                         core::ptr::null_mut(), pl.len(), sys::CHEETAH_PROJECTIVE)
+        };
+        ctx.check(rc)?;
+        Ok(out.iter().map(|l| ProjectivePoint::from_raw_coordinates([six(&l[..6]), six(&l[6..12]), six(&l[12..])])).collect())
+    }
+
+    /// Variable-time form, the reference's own (X : Y : Z) as well  (ProjectivePoint::multiply_vartime).
+    pub fn multiply_vartime_batch(ctx: &mut GpuContext, points: &[ProjectivePoint], scalars: &[Scalar]) -> Result<Vec<ProjectivePoint>, BatchError> {
+        assert_eq!(points.len(), scalars.len());
+        let (pl, kb) = (projective_limbs(points), scalar_bytes(scalars));
+        let mut out = vec![[0u64; 18]; pl.len()];
+        let rc = unsafe {
+            sys::cheetah_multiply_vartime_batch(ctx.0, pl.as_ptr().cast(), sys::CHEETAH_PROJECTIVE, kb.as_ptr().cast(),
+                                                out.as_mut_ptr().cast(), core::ptr::null_mut(), pl.len(), sys::CHEETAH_PROJECTIVE)
+        };
+        ctx.check(rc)?;
+        Ok(out.iter().map(|l| ProjectivePoint::from_raw_coordinates([six(&l[..6]), six(&l[6..12]), six(&l[12..])])).collect())
+    }
+
+    /// out[i] = by_self[i] * points[i] + by_basepoint[i] * G as affine points: the verification equation of a batch of
+    /// Schnorr signatures  (ProjectivePoint::multiply_double_with_basepoint_vartime, then AffinePoint::from).
+    pub fn multiply_double_with_basepoint_vartime_batch(ctx: &mut GpuContext, points: &[AffinePoint], by_self: &[Scalar],
+                                                        by_basepoint: &[Scalar]) -> Result<Vec<AffinePoint>, BatchError> {
+        assert_eq!(points.len(), by_self.len());
+        assert_eq!(points.len(), by_basepoint.len());
+        let pl = affine_limbs(points);
+        let mut kb = Vec::with_capacity(2 * points.len());
+        for (a, b) in by_self.iter().zip(by_basepoint) {
+            kb.push(a.to_bytes());
+            kb.push(b.to_bytes());
+        }
+        let mut xy = vec![[0u64; 12]; pl.len()];
+        let mut inf = vec![0u8; pl.len()];
+        let rc = unsafe {
+            sys::cheetah_multiply_double_with_basepoint_vartime_batch(ctx.0, pl.as_ptr().cast(), sys::CHEETAH_AFFINE, kb.as_ptr().cast(),
+                                                                      xy.as_mut_ptr().cast(), inf.as_mut_ptr(), pl.len(), sys::CHEETAH_AFFINE)
+        };
+        ctx.check(rc)?;
+        Ok(affine_from(&xy, &inf))
+    }
+
+    /// n points shaped like ProjectivePoint::random (x drawn, y = +-sqrt(x^3 + x + B), cofactor cleared), from a seed
+    /// instead of an rng: element i is a function of (seed, start + i) only.
+    pub fn random_batch(ctx: &mut GpuContext, seed: u64, start: u64, n: usize) -> Result<Vec<ProjectivePoint>, BatchError> {
+        let mut out = vec![[0u64; 18]; n];
+        let rc = unsafe {
+            sys::cheetah_random_points(ctx.0, seed, start, out.as_mut_ptr().cast(), core::ptr::null_mut(), n, sys::CHEETAH_PROJECTIVE)
         };
         ctx.check(rc)?;
         Ok(out.iter().map(|l| ProjectivePoint::from_raw_coordinates([six(&l[..6]), six(&l[6..12]), six(&l[12..])])).collect())

@@ -118,6 +118,41 @@ int main() {
             batch_normalize(ctx, chk4, q, infinity);
             EXPECT(q[0].x.c == g4[0].x.c && q[0].y.c == g4[0].y.c && q[1].x.c == g4[0].x.c && q[1].y.c == g4[0].y.c);
         }
+        // round 3's widening: Fp::sqrt KATs (src/fp.rs:899-910: sqrt(0) = 0, sqrt(1) = 1, 7 is not a square), Fp::exp
+        // (a^(p-2) a = 1, :914-934), Fp6::exp (a^0 = 1, a^1 = a, a^2 = a.square(); the long exponents are compared with
+        // the oracle in tests/test_gpu_widening.py), seeded random points (on the curve's prime-order subgroup, the affine
+        // and the projective form of one stream the same points, a window of a stream the same elements)
+        {
+            const uint64_t P = 0xFFFFFFFF00000001ull;
+            std::vector<uint8_t> some;
+            auto r = fp_sqrt_batch(ctx, {0, 1, 7, 4, P + 1}, some);
+            EXPECT(some[0] == 1 && r[0] == 0 && some[1] == 1 && r[1] == 1 && some[2] == 0 && some[3] == 1 && (r[3] == 2 || r[3] == P - 2));
+            EXPECT(some[4] == 1 && r[4] == 1);
+            auto e = fp_exp_batch(ctx, {3, 5, P - 1}, P - 2);
+            auto back = fp6_mul_batch(ctx, {Fp6{{e[0], 0, 0, 0, 0, 0}}, Fp6{{e[1], 0, 0, 0, 0, 0}}}, {Fp6{{3, 0, 0, 0, 0, 0}}, Fp6{{5, 0, 0, 0, 0, 0}}});
+            EXPECT(back[0].c == one.c && back[1].c == one.c && e[2] == P - 1);
+            auto p1 = fp6_exp_batch(ctx, {a, b}, {1, 0, 0, 0, 0, 0});
+            auto p0 = fp6_exp_batch(ctx, {a, b}, {0, 0, 0, 0, 0, 0});
+            auto p2 = fp6_exp_batch(ctx, {a, b}, {2, 0, 0, 0, 0, 0});
+            auto sq = fp6_square_batch(ctx, {a, b});
+            EXPECT(p1[0].c == fp6_mul_batch(ctx, {a}, {one})[0].c && p0[0].c == one.c && p0[1].c == one.c && p2[0].c == sq[0].c && p2[1].c == sq[1].c);
+            std::vector<uint8_t> rinf;
+            auto ra = random_affine_batch(ctx, 77, 300, rinf);
+            auto rp = random_projective_batch(ctx, 77, 300);
+            std::vector<AffinePoint> rq;
+            std::vector<uint8_t> rqinf;
+            batch_normalize(ctx, rp, rq, rqinf);
+            auto tf = is_torsion_free_batch(ctx, rp);
+            bool same = true, free_ = true, none_inf = true;
+            for (size_t i = 0; i < ra.size(); i++) {
+                same = same && ra[i].x.c == rq[i].x.c && ra[i].y.c == rq[i].y.c;
+                free_ = free_ && tf[i] == 1;
+                none_inf = none_inf && rinf[i] == 0 && rqinf[i] == 0;
+            }
+            EXPECT(same && free_ && none_inf);
+            auto ra2 = random_affine_batch(ctx, 77, 10, rinf, 100);          // a later window of the same stream
+            EXPECT(ra2[0].x.c == ra[100].x.c && ra2[9].y.c == ra[109].y.c);
+        }
         // length mismatch is an error, not UB
         bool threw = false;
         try {

@@ -126,6 +126,11 @@ def test_random_points_are_the_reference_construction(eng, ora):
     # the stream is addressed by element: a later window of it is the same points
     xy2, _ = eng.random_points(seed, 100, start + 250, AFFINE)
     assert (host(xy2) == host(xy)[250:350]).all()
+    # the host-pointer entry point fills numpy arrays with the same stream
+    for form in (AFFINE, PROJECTIVE):
+        hxy, hinf = eng.random_points(seed, 300, start, form, host=True)
+        dxy, dinf = eng.random_points(seed, 300, start, form)
+        assert isinstance(hxy, np.ndarray) and (hxy == host(dxy)).all() and (hinf == host(dinf)).all()
     other, _ = eng.random_points(seed + 1, 100, start, AFFINE)
     assert (host(other) != host(xy)[:100]).any(axis=1).all()
 
