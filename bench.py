@@ -464,7 +464,7 @@ def main():
                          "frac_if_credited_as_ProjectivePoint_multiply": achieved * MAD32_PER_CT_MULT_PROJECTIVE / MAD32_PER_CT_MULT / mad_peak,
                          "note": "achieved = reference-algorithm mad32 count of AffinePoint::multiply (72588 Fp mul x 4) x units / "
                                  "HIP-event launch time; peak = v_mad_u64_u32 issue rate measured live on this device; the kernel "
-                                 "is VALU-issue bound (profiles/, DESIGN.md 5): carries and reductions issue at the same rate as the mads; "
+                                 "is VALU-issue bound (profiles/, DESIGN.md 2, 5): a carry-class instruction takes 0.85-0.95 of a mad's issue time and there are as many of them; "
                                  "ceiling_frac = credited mad32 / the formulation's floor in mad issue slots (bench.py ceiling_model, DESIGN.md 5); "
                                  "ms_per_launch / units_per_launch are per k_multiply_ct kernel launch (the library bounds each launch); "
                                  "traffic = (FETCH_SIZE + WRITE_SIZE) per unit from the rocprofv3 PMC passes in profiles/ x units_per_launch: "
