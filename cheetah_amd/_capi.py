@@ -28,6 +28,7 @@ SIGNATURES = {
     "cheetah_basepoint_table_read": (C.c_int32, [_vp, _vp, _vp, _sz]),
     "cheetah_is_on_curve_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),
     "cheetah_debug_set_reference_schedule": (C.c_int32, [_vp, _i]),
+    "cheetah_ctx_set_point_independent_tables": (C.c_int32, [_vp, _i]),
     "cheetah_add_batch": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _sz]),
     "cheetah_add_batch_dev": (C.c_int32, [_vp, _vp, _i, _vp, _i, _vp, _sz]),
     "cheetah_double_batch": (C.c_int32, [_vp, _vp, _i, _vp, _sz]),

@@ -56,6 +56,9 @@ struct DeviceTables {
     // Fixed-base table of k_mul_by_generator_wide (affine results only; no counterpart in the reference):
     // wide[j][e] = (e + 1) 64^j G, window-major, entry-major, x|y.
     u64 wide[43 * 32 * 12];
+    // bit 0: cheetah_ctx_set_point_independent_tables -- the constant-time ladders build EVERY wave's window tables with
+    // the reference's complete additions (no wave-level choice that depends on the points)
+    u64 flags;
 };
 constexpr int WIDE_BITS = 6, WIDE_WINDOWS = 43, WIDE_ENTRIES = 32, WIDE_BLOCK = 1024;
 
@@ -238,6 +241,7 @@ CH_DEV Proj load_input_point(const u64* pts, size_t i) {
 constexpr int BUILD_TABLES_THREADS = 256;
 __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTables* tab, const u64* gen_xy, const u64* shift_xy) {
     const int t = threadIdx.x;
+    if (t == 0) tab->flags = 0;
     if (t < 32) {
         // BASEPOINT_TABLE itself is built by k_build_comb_table (shared with BasePointTable::create for any base)
     } else if (t == 32) {
@@ -1029,7 +1033,8 @@ CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* 
 // its multiply_vartime() returns the identity -- every entry of its NafLookupTable stays at z = 0.  With NAF_IDENTITY
 // such an input is replaced by (0, 1, 0), whose table is all identities, so the fast path agrees with the NAF ladder.
 template <int IN_FORM, bool NAF_IDENTITY = false>
-CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
+CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t,
+                              bool reference_only = false) {
     Affine pa;
     if (IN_FORM == 1) {
         pa = affine_from_proj(load_proj(pts + 18 * i));
@@ -1043,8 +1048,11 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
     // its multiples on another curve, while the reference's complete additions (which use 3B) produce other values --
     // and those are what LookupTable::from returns (such inputs exist: from_uncompressed_unchecked, unchecked decoding).
     // An off-curve lane therefore sends its wave to the reference's construction as well (2 S + 1 M per lane).
-    bool ok = pa.inf || affine_on_curve(pa.x, pa.y);
-    ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t) && ok;
+    bool ok = false;
+    if (!reference_only) {  // wave-uniform (a flag of the context)
+        ok = pa.inf || affine_on_curve(pa.x, pa.y);
+        ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t) && ok;
+    }
     if (__any(!ok)) {
         Proj p = load_input_point<IN_FORM>(pts, i);
         if (IN_FORM == 1 && NAF_IDENTITY && fp6_is_zero(p.z)) p = proj_identity();
@@ -1134,7 +1142,7 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
         // ladders, fed by different tables, disagree), belongs to the NAF kernel (ONLY_WIDE, the same predicate)
         if (DIRECT && __any((int)(k[3] >> 63) | (int)!point_on_curve<IN_FORM>(pts, ii))) continue;
         const int n_entries = __any(wide) ? 16 : 8;
-        const u32 ident = build_lookup_table<IN_FORM, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_lookup_table<IN_FORM, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, !DIRECT && (tab->flags & 1));
         const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
@@ -1507,7 +1515,8 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
         if (DIRECT && __any(wide)) continue;  // top nibble > 7 <=> bit 255 set: this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
         for (int j = 0; j < m; j++) {
-            s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, DIRECT>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
+            s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, DIRECT>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t,
+                                                                        !DIRECT && (tab->flags & 1));
         }
         ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S
         for (int w = 63; w >= 0; w--) {

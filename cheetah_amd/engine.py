@@ -666,6 +666,11 @@ class Engine:
         CU slots between launches)."""
         self._check(self._lib.cheetah_ctx_set_launch_rounds(self._h, int(rounds)))
 
+    def set_point_independent_tables(self, on):
+        """Constant-time ladders: build every wave's window tables by the reference's construction, so that timing does
+        not depend on the points either (same results, 4 % slower; off by default)."""
+        self._check(self._lib.cheetah_ctx_set_point_independent_tables(self._h, int(bool(on))))
+
     def set_reference_schedule(self, on):
         """Tests / tools: run multiply_double_with_basepoint_vartime's affine results by the reference's Straus NAF
         schedule instead of the composed one (same results)."""

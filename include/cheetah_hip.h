@@ -222,12 +222,23 @@ int32_t cheetah_basepoint_table_read(cheetah_ctx *ctx, const cheetah_basepoint_t
  * independence of the POINTS: a wave that holds the identity, a point of order <= 16 or a point that is not on the
  * curve rebuilds its window tables with the reference's complete additions (src/lookup.rs:25-37) instead of the
  * shared-inversion affine steps, and a wave that holds a scalar with the top nibble > 7 (no canonical scalar) builds
- * 16 table entries instead of 8.  The reference's LookupTable::from has neither branch.
+ * 16 table entries instead of 8.  The reference's LookupTable::from has neither branch;
+ * cheetah_ctx_set_point_independent_tables removes the first.
+ * cheetah_multiply_vartime_batch with a PROJECTIVE / JACOBIAN out_form runs a scheduling loop (every wave regroups its
+ * 128 items by the step they want next); the loop has a hard bound on its phases, far above what any scalar needs
+ * (tools/naf_pool_sim.py, tests/test_naf_pool_cpu.py), so that a defect could never spin on the GPU: an item left
+ * unfinished at the bound would be returned as zero limbs with inf[i] = 0xFE.  No input produces that value.
  * Points are not required to be on the curve (the reference does not check either): such inputs return what the
  * reference's formulas return for them, by the reference's own table construction and, for the vartime entry
  * points, its own NAF schedule (tests/test_gpu_boundary.py). */
 int32_t cheetah_multiply_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
                                uint64_t *out, uint8_t *inf, size_t n, int out_form);
+/* on != 0: the constant-time ladders (cheetah_multiply_batch, cheetah_multiply_many_batch and their _dev / _noalloc
+ * forms) build every wave's window tables by the reference's own construction (LookupTable::from, complete additions,
+ * src/lookup.rs:25-37), so that no wave-level choice depends on the points either; same results, 4 % slower
+ * (measured at 2^22: 29.2 against 30.3 M/s, profiles/r03_point_independent_tables.txt).
+ * Off by default.  Applies to every device of the context; blocks until the setting is in place. */
+int32_t cheetah_ctx_set_point_independent_tables(cheetah_ctx *ctx, int on);
 int32_t cheetah_multiply_vartime_batch(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,
                                        uint64_t *out, uint8_t *inf, size_t n, int out_form);
 int32_t cheetah_multiply_batch_dev(cheetah_ctx *ctx, const uint64_t *pts, int in_form, const uint8_t *scalars32,

@@ -446,3 +446,39 @@ def test_off_curve_inputs_match_the_reference_through_every_ladder(eng, ora):
         want, winf = ora.multiply_many_batch(arr, form, kk, 1, 0, vartime=True, with_basepoint=True)
         got, ginf = eng.multiply_double_with_basepoint_vartime_batch(dev(arr), dev(kk), form, AFFINE)
         assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, "with_basepoint")
+
+
+def test_point_independent_tables_return_the_same_results(eng, ora):
+    """cheetah_ctx_set_point_independent_tables: every wave of the constant-time ladders builds its window tables the
+    reference's way (LookupTable::from, src/lookup.rs:25-37) instead of choosing per wave.  Ordinary points, identities,
+    a point off the curve and wide scalars in one batch, all forms, single- and multi-scalar: bit-equal to the oracle
+    with the switch on, and to the default path."""
+    n = 300
+    pts = points(eng, 81, n)
+    pts[7] = IDENT
+    pts[70, 3] ^= np.uint64(6)                          # off the curve
+    k = synth.scalars(82, n).copy()
+    k[5] = 0xFF
+    k[6] = 0
+    lam = synth.fp6_elements(83, n)
+    prj = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), lam), eng.fp6_mul_batch(pts[:, 6:].copy(), lam), lam], axis=1)
+    prj[7, 12:] = 0
+    base = {}
+    for arr, form, out_form in ((pts, AFFINE, AFFINE), (pts, AFFINE, JACOBIAN), (prj, PROJECTIVE, PROJECTIVE), (prj, PROJECTIVE, AFFINE)):
+        base[(form, out_form)] = tuple(host(x) for x in eng.multiply_batch(dev(arr), dev(k), form, out_form))
+    base["many"] = tuple(host(x) for x in eng.multiply_many_batch(dev(pts), dev(k), 2, AFFINE, AFFINE))
+    eng.set_point_independent_tables(True)
+    try:
+        for arr, form, out_form in ((pts, AFFINE, AFFINE), (pts, AFFINE, JACOBIAN), (prj, PROJECTIVE, PROJECTIVE), (prj, PROJECTIVE, AFFINE)):
+            want, winf = ora.multiply_batch(arr, form, k, out_form, vartime=False)
+            got, ginf = (host(x) for x in eng.multiply_batch(dev(arr), dev(k), form, out_form))
+            assert (got == want).all() and (ginf == winf).all(), (form, out_form)
+            assert (got == base[(form, out_form)][0]).all() and (ginf == base[(form, out_form)][1]).all()
+        got, ginf = (host(x) for x in eng.multiply_many_batch(dev(pts), dev(k), 2, AFFINE, AFFINE))
+        assert (got == base["many"][0]).all() and (ginf == base["many"][1]).all()
+        # the vartime entry points do not look at the switch
+        want, winf = ora.multiply_batch(pts, AFFINE, k, AFFINE, vartime=True)
+        got, ginf = (host(x) for x in eng.multiply_vartime_batch(dev(pts), dev(k), AFFINE, AFFINE))
+        assert (got == want).all() and (ginf == winf).all()
+    finally:
+        eng.set_point_independent_tables(False)
