@@ -1,0 +1,379 @@
+"""A second leg for parity level L2 (the reference's own (X : Y : Z) / (X, Y, Z) representative).
+
+The reference holds no known-answer vector for a projective or Jacobian REPRESENTATIVE -- every vector in its tests is
+an affine point -- so L2 rested on the oracle restating its formula sequences line by line.  The formulas the
+reference implements are published, and each has a closed form: three polynomials in the input coordinates that do
+not depend on statement order, temporaries or small-constant tricks.  This file evaluates those closed forms with the
+independent big-integer Fp6 model (oracle/model.py: schoolbook products mod u^6 - 7, Python integers) and requires the
+oracle's step-by-step restatement to produce exactly those values, limb for limb, on random inputs -- arbitrary field
+elements, not only points of the curve: the closed forms are polynomial identities.
+
+  ProjectivePoint::add / add_mixed               Renes-Costello-Batina 2015, complete formulas for y^2 z = x^3 + a x z^2 + b z^3
+                                                (src/curve/projective.rs:456-569), a = 1, b = u + 395
+  ProjectivePoint::double                        Handbook of Elliptic and Hyperelliptic Curve Cryptography 13.2, projective
+                                                (src/curve/projective.rs:349-393)
+  JacobianPoint::add / add_mixed / double       Handbook of Elliptic and Hyperelliptic Curve Cryptography 13.2
+                                                (src/curve/jacobian.rs:368-402, :452-552)
+  the unchecked forms                           the same polynomials without the special-case selections
+The GPU is compared with the oracle bit for bit (tests/test_gpu_group_law.py, test_gpu_parity.py), so this carries over.
+Bar: bit-exact."""
+import numpy as np
+
+from oracle import model as M
+
+AFFINE, PROJECTIVE, JACOBIAN = 0, 1, 2
+A = M.ONE                                   # curve coefficient a = 1
+B3 = M.f6_scale(M.B, 3)
+
+
+def _rand_fp6(rng, n):
+    out = rng.integers(0, M.P, (n, 6), dtype=np.uint64)
+    out[0] = [M.P - 1] * 6                   # extreme limbs
+    out[1, :] = 0
+    out[1, 0] = 1
+    return out
+
+
+def _t(row):
+    return tuple(int(v) for v in row)
+
+
+def _mul(*xs):
+    r = xs[0]
+    for x in xs[1:]:
+        r = M.f6_mul(r, x)
+    return r
+
+
+def _add(*xs):
+    r = xs[0]
+    for x in xs[1:]:
+        r = M.f6_add(r, x)
+    return r
+
+
+def rcb_add(p, q):
+    """closed form of the complete addition (RCB15 section 3, general a)"""
+    (x1, y1, z1), (x2, y2, z2) = p, q
+    xy = _add(_mul(x1, y2), _mul(x2, y1))
+    yz = _add(_mul(y1, z2), _mul(y2, z1))
+    xz = _add(_mul(x1, z2), _mul(x2, z1))
+    xx, yy, zz = _mul(x1, x2), _mul(y1, y2), _mul(z1, z2)
+    t = _add(_mul(A, xz), _mul(B3, zz))                              # a (x1 z2 + x2 z1) + 3b z1 z2
+    s = M.f6_sub(_add(_mul(A, xx), _mul(B3, xz)), _mul(A, A, zz))    # a x1 x2 + 3b (x1 z2 + x2 z1) - a^2 z1 z2
+    w = _add(M.f6_scale(xx, 3), _mul(A, zz))                         # 3 x1 x2 + a z1 z2
+    x3 = M.f6_sub(_mul(xy, M.f6_sub(yy, t)), _mul(yz, s))
+    y3 = _add(_mul(w, s), _mul(_add(yy, t), M.f6_sub(yy, t)))
+    z3 = _add(_mul(yz, _add(yy, t)), _mul(xy, w))
+    return x3, y3, z3
+
+
+def hehcc_proj_double(p):
+    """projective tangent formula, HEHCC 13.2 (the reference's ProjectivePoint::double is this one, not RCB15's):
+    A = a Z^2 + 3 X^2, B = Y Z, C = X Y B, D = A^2 - 8 C;  X3 = 2 B D, Y3 = A (4 C - D) - 8 Y^2 B^2, Z3 = 8 B^3"""
+    x, y, z = p
+    a = _add(_mul(A, z, z), M.f6_scale(_mul(x, x), 3))
+    b = _mul(y, z)
+    c = _mul(x, y, b)
+    d = M.f6_sub(_mul(a, a), M.f6_scale(c, 8))
+    x3 = M.f6_scale(_mul(b, d), 2)
+    y3 = M.f6_sub(_mul(a, M.f6_sub(M.f6_scale(c, 4), d)), M.f6_scale(_mul(y, y, b, b), 8))
+    return x3, y3, M.f6_scale(_mul(b, b, b), 8)
+
+
+def hehcc_add(p, q):
+    """Jacobian chord formula, HEHCC 13.2: A = X1 Z2^2, B = X2 Z1^2, C = Y1 Z2^3, D = Y2 Z1^3, E = B - A, F = D - C"""
+    (x1, y1, z1), (x2, y2, z2) = p, q
+    a = _mul(x1, z2, z2)
+    b = _mul(x2, z1, z1)
+    c = _mul(y1, z2, z2, z2)
+    d = _mul(y2, z1, z1, z1)
+    e, f = M.f6_sub(b, a), M.f6_sub(d, c)
+    e2, e3 = _mul(e, e), _mul(e, e, e)
+    x3 = M.f6_sub(M.f6_sub(_mul(f, f), e3), M.f6_scale(_mul(a, e2), 2))
+    y3 = M.f6_sub(_mul(f, M.f6_sub(_mul(a, e2), x3)), _mul(c, e3))
+    return x3, y3, _mul(z1, z2, e)
+
+
+def hehcc_double(p):
+    """Jacobian tangent formula, HEHCC 13.2, a = 1: A = 4 X Y^2, B = 3 X^2 + a Z^4"""
+    x, y, z = p
+    a = M.f6_scale(_mul(x, y, y), 4)
+    b = _add(M.f6_scale(_mul(x, x), 3), _mul(A, z, z, z, z))
+    x3 = M.f6_sub(_mul(b, b), M.f6_scale(a, 2))
+    y3 = M.f6_sub(_mul(b, M.f6_sub(a, x3)), M.f6_scale(_mul(y, y, y, y), 8))
+    return x3, y3, M.f6_scale(_mul(y, z), 2)
+
+
+def _rows(x, y, z):
+    return np.ascontiguousarray(np.concatenate([x, y, z], axis=1))
+
+
+def _expect(want_rows, got, what):
+    want = np.array([list(w[0]) + list(w[1]) + list(w[2]) for w in want_rows], np.uint64)
+    bad = np.nonzero((want != got).any(axis=1))[0]
+    assert len(bad) == 0, "%s: oracle differs from the closed form at rows %s" % (what, bad[:5])
+
+
+def test_projective_formulas_are_the_published_closed_forms(ora):
+    rng = np.random.default_rng(2015)
+    n = 48
+    x1, y1, z1, x2, y2, z2 = (_rand_fp6(rng, n) for _ in range(6))
+    p, q = _rows(x1, y1, z1), _rows(x2, y2, z2)
+    pt = [(_t(x1[i]), _t(y1[i]), _t(z1[i])) for i in range(n)]
+    qt = [(_t(x2[i]), _t(y2[i]), _t(z2[i])) for i in range(n)]
+    _expect([rcb_add(a, b) for a, b in zip(pt, qt)], ora.add_batch(p, PROJECTIVE, q, PROJECTIVE), "ProjectivePoint::add")
+    _expect([hehcc_proj_double(a) for a in pt], ora.double_batch(p, PROJECTIVE), "ProjectivePoint::double")
+    # add_mixed: the same polynomials at z2 = 1 (the affine operand is not the identity here)
+    qa = np.ascontiguousarray(np.concatenate([x2, y2], axis=1))
+    _expect([rcb_add(a, (b[0], b[1], M.ONE)) for a, b in zip(pt, qt)], ora.add_batch(p, PROJECTIVE, qa, AFFINE), "ProjectivePoint::add_mixed")
+    # double_multi(3) = three doublings; the unchecked forms agree with the checked ones away from z = 0
+    want = [hehcc_proj_double(hehcc_proj_double(hehcc_proj_double(a))) for a in pt]
+    _expect(want, ora.double_multi_batch(p, PROJECTIVE, 3), "ProjectivePoint::double_multi(3)")
+    _expect(want, ora.double_multi_unchecked_batch(p, PROJECTIVE, 3), "ProjectivePoint::double_multi_unchecked(3)")
+
+
+def test_jacobian_formulas_are_the_handbook_closed_forms(ora):
+    rng = np.random.default_rng(2005)
+    n = 48
+    x1, y1, z1, x2, y2, z2 = (_rand_fp6(rng, n) for _ in range(6))
+    z1[1] = rng.integers(1, M.P, 6, dtype=np.uint64)      # z = 0 would select the identity: not what is checked here
+    z1[0, 0] -= np.uint64(1)
+    p, q = _rows(x1, y1, z1), _rows(x2, y2, z2)
+    pt = [(_t(x1[i]), _t(y1[i]), _t(z1[i])) for i in range(n)]
+    qt = [(_t(x2[i]), _t(y2[i]), _t(z2[i])) for i in range(n)]
+    _expect([hehcc_add(a, b) for a, b in zip(pt, qt)], ora.add_batch(p, JACOBIAN, q, JACOBIAN), "JacobianPoint::add")
+    _expect([hehcc_double(a) for a in pt], ora.double_batch(p, JACOBIAN), "JacobianPoint::double")
+    qa = np.ascontiguousarray(np.concatenate([x2, y2], axis=1))
+    want = [hehcc_add(a, (b[0], b[1], M.ONE)) for a, b in zip(pt, qt)]
+    _expect(want, ora.add_batch(p, JACOBIAN, qa, AFFINE), "JacobianPoint::add_mixed")
+    _expect(want, ora.add_mixed_unchecked_batch(p, JACOBIAN, qa), "JacobianPoint::add_mixed_unchecked")
+    want = [hehcc_double(hehcc_double(a)) for a in pt]
+    _expect(want, ora.double_multi_batch(p, JACOBIAN, 2), "JacobianPoint::double_multi(2)")
+    _expect(want, ora.double_multi_unchecked_batch(p, JACOBIAN, 2), "JacobianPoint::double_multi_unchecked(2)")
+
+
+def hehcc_proj_add_mixed(p, q):
+    """projective chord formula with an affine operand, HEHCC 13.2: u = Y2 Z1 - Y1, v = X2 Z1 - X1,
+    A = u^2 Z1 - v^3 - 2 v^2 X1;  X3 = v A, Y3 = u (v^2 X1 - A) - v^3 Y1, Z3 = v^3 Z1"""
+    (x1, y1, z1), (x2, y2) = p, q
+    u = M.f6_sub(_mul(y2, z1), y1)
+    v = M.f6_sub(_mul(x2, z1), x1)
+    v2, v3 = _mul(v, v), _mul(v, v, v)
+    a = M.f6_sub(M.f6_sub(_mul(u, u, z1), v3), M.f6_scale(_mul(v2, x1), 2))
+    return _mul(v, a), M.f6_sub(_mul(u, M.f6_sub(_mul(v2, x1), a)), _mul(v3, y1)), _mul(v3, z1)
+
+
+def _radix16(k):
+    """Scalar::bytes_to_radix_16 (src/scalar.rs:531-548): digits in [-8, 8), the last one un-recentred"""
+    d = [(k >> (4 * i)) & 15 for i in range(64)]
+    for i in range(63):
+        carry = (d[i] + 8) >> 4
+        d[i] -= carry << 4
+        d[i + 1] += carry
+    return d
+
+
+def _wnaf5(k):
+    """Scalar::bytes_to_wnaf_vartime(by, 5) for k < 2^255 (src/scalar.rs:585-643), one digit per bit position"""
+    d = [0] * 257
+    pos = 0
+    while k:
+        if k & 1:
+            z = k & 31
+            if z >= 16:
+                z -= 32
+            d[pos] = z
+            k -= z
+        k >>= 1
+        pos += 1
+    return d[:256]
+
+
+def _ladder(pt, k, vartime, dbl, add_mixed):
+    """{Projective,Jacobian}Point::multiply / multiply_vartime as the reference composes them (src/curve/projective.rs:
+    614-662, src/curve/jacobian.rs:599-649): from the shift point S, doublings and mixed additions of table entries,
+    then - 2^256 S (multiply_vartime too: its "skip unset digits" loop never moves off 255).  The table entries are
+    affine points (LookupTable / NafLookupTable hold AffinePoints), hence unique values: the model's textbook j P."""
+    neg = lambda q: (q[0], M.f6_neg(q[1]))
+    acc = (M.SHIFT_POINT[0], M.SHIFT_POINT[1], M.ONE)
+    mshift = neg(M.scalar_mul(1 << 256, M.SHIFT_POINT))
+    table = {}
+
+    def entry(j):
+        if j not in table:
+            table[j] = M.scalar_mul(j, pt)
+        return table[j]
+
+    def add(acc, d):
+        if d == 0:
+            return acc                                   # the identity operand: add_mixed_unchecked returns self
+        q = entry(abs(d))
+        return add_mixed(acc, neg(q) if d < 0 else q)
+
+    if vartime:
+        digits = _wnaf5(k)
+        for j in range(255, -1, -1):
+            acc = dbl(acc)
+            acc = add(acc, digits[j])
+    else:
+        digits = _radix16(k)
+        for i in range(63, -1, -1):
+            for _ in range(4):
+                acc = dbl(acc)
+            acc = add(acc, digits[i])
+    return add_mixed(acc, mshift)
+
+
+def test_ladder_representatives_are_compositions_of_the_closed_forms(ora):
+    """The (X : Y : Z) of ProjectivePoint::multiply / multiply_vartime and the (X, Y, Z) of JacobianPoint::multiply /
+    multiply_vartime, recomputed from the closed forms, the model's affine multiples and Python's integers alone, equal
+    the oracle's limb for limb -- L2 for the ladders, on a leg that shares no code with the oracle."""
+    rng = np.random.default_rng(11)
+    g = ora.table("ora_generator_affine", 1)[0]
+    base = M.scalar_mul(int(rng.integers(2, 2**62)), (_t(g[:6]), _t(g[6:])))      # some point of the subgroup
+    pts = np.array([list(base[0]) + list(base[1])], np.uint64)
+    scalars = [1, 16, 0x0f0f0f0f0f, int.from_bytes(rng.bytes(32), "little") >> 1, M.Q - 1]
+    jac_add_mixed = lambda p, q: hehcc_add(p, (q[0], q[1], M.ONE))
+    for k in scalars:
+        kb = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8).reshape(1, 32)
+        for vt in (False, True):
+            want = _ladder(base, k, vt, hehcc_proj_double, hehcc_proj_add_mixed)
+            got, _ = ora.multiply_batch(pts, AFFINE, kb, PROJECTIVE, vartime=vt)
+            assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [want[0], want[1], want[2]], ("projective", k, vt)
+            want = _ladder(base, k, vt, hehcc_double, jac_add_mixed)
+            got, _ = ora.multiply_batch(pts, AFFINE, kb, JACOBIAN, vartime=vt)
+            assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [want[0], want[1], want[2]], ("jacobian", k, vt)
+    # the input's own representative does not show in the result (the tables are normalised): a projective and a
+    # Jacobian input with a random z give the same (X : Y : Z) / (X, Y, Z)
+    z = _t(rng.integers(1, M.P, 6, dtype=np.uint64))
+    k = scalars[3]
+    kb = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8).reshape(1, 32)
+    prj = np.array([list(_mul(base[0], z)) + list(_mul(base[1], z)) + list(z)], np.uint64)
+    jac = np.array([list(_mul(base[0], z, z)) + list(_mul(base[1], z, z, z)) + list(z)], np.uint64)
+    for vt in (False, True):
+        want = _ladder(base, k, vt, hehcc_proj_double, hehcc_proj_add_mixed)
+        got, _ = ora.multiply_batch(prj, PROJECTIVE, kb, PROJECTIVE, vartime=vt)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [want[0], want[1], want[2]], ("projective in", vt)
+        want = _ladder(base, k, vt, hehcc_double, jac_add_mixed)
+        got, _ = ora.multiply_batch(jac, JACOBIAN, kb, JACOBIAN, vartime=vt)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [want[0], want[1], want[2]], ("jacobian in", vt)
+
+
+def test_basepoint_table_representative_is_a_composition_of_the_closed_forms(ora):
+    """BasePointTable::multiply (src/lookup.rs:189-206): from S, the 32 odd radix-16 digits through the tables of
+    256^(i/2) G, four doublings, the 32 even digits, then - 2^4 S -- its (X : Y : Z) from the closed forms and the
+    model's affine multiples, against the oracle's `&BASEPOINT_TABLE * &Scalar`."""
+    rng = np.random.default_rng(12)
+    g = ora.table("ora_generator_affine", 1)[0]
+    G = (_t(g[:6]), _t(g[6:]))
+    neg = lambda q: (q[0], M.f6_neg(q[1]))
+    mshift4 = neg(M.scalar_mul(16, M.SHIFT_POINT))
+    cache = {}
+
+    def entry(i, d):                                      # tables[i / 2].get_point(d) = d 256^(i/2) G
+        key = (i // 2, abs(d))
+        if key not in cache:
+            cache[key] = M.scalar_mul(abs(d) << (8 * (i // 2)), G)
+        return neg(cache[key]) if d < 0 else cache[key]
+
+    for k in (1, 0x1111, int.from_bytes(rng.bytes(32), "little") >> 2, M.Q - 1):
+        a = _radix16(k)
+        acc = (M.SHIFT_POINT[0], M.SHIFT_POINT[1], M.ONE)
+        for i in range(1, 64, 2):
+            if a[i]:
+                acc = hehcc_proj_add_mixed(acc, entry(i, a[i]))
+        for _ in range(4):
+            acc = hehcc_proj_double(acc)
+        for i in range(0, 64, 2):
+            if a[i]:
+                acc = hehcc_proj_add_mixed(acc, entry(i, a[i]))
+        acc = hehcc_proj_add_mixed(acc, mshift4)
+        kb = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8).reshape(1, 32)
+        got, _ = ora.mul_by_generator_batch(kb, PROJECTIVE)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], k
+
+
+def test_a_ladder_is_its_formula_sequence(ora):
+    """ProjectivePoint::multiply's (X : Y : Z), composed here from the closed forms alone for a short scalar: the
+    radix-16 ladder from the shift point S with LookupTable entries j P (src/curve/projective.rs:614-625,
+    src/lookup.rs:25-37, :189-206), on the model's affine points and integers -- then compared with the oracle's
+    multiply_batch as AFFINE points (the representative of the full ladder involves the table's normalisation, which
+    the closed forms above do not cover; the affine point does not)."""
+    rng = np.random.default_rng(7)
+    g = ora.table("ora_generator_affine", 1)[0]
+    pt = (_t(g[:6]), _t(g[6:]))
+    for k in (1, 2, 15, 16, 0x1234567, int(rng.integers(1, 2**62))):
+        want = M.scalar_mul(k, pt)
+        kb = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8).reshape(1, 32)
+        for vt in (False, True):
+            got, inf = ora.multiply_batch(g.reshape(1, 12), AFFINE, kb, AFFINE, vartime=vt)
+            assert inf[0] == 0 and _t(got[0, :6]) == want[0] and _t(got[0, 6:]) == want[1], (k, vt)
+
+
+def _wnaf(k, w):
+    """Scalar::bytes_to_wnaf_vartime(by, w) for k < 2^255 (src/scalar.rs:585-643)"""
+    d = [0] * 258
+    pos = 0
+    while k:
+        if k & 1:
+            z = k & ((1 << w) - 1)
+            if z >= 1 << (w - 1):
+                z -= 1 << w
+            d[pos] = z
+            k -= z
+        k >>= 1
+        pos += 1
+    return d[:256]
+
+
+def test_multi_scalar_representatives_are_compositions_of_the_closed_forms(ora):
+    """ProjectivePoint::multiply_many / multiply_many_vartime (src/curve/projective.rs:817-869; m = 2 is multiply_double)
+    and multiply_double_with_basepoint_vartime (:756-809, by_basepoint through a width-8 NAF and the odd multiples of G):
+    shared doublings, the additions in index order -- their (X : Y : Z) from the closed forms."""
+    rng = np.random.default_rng(13)
+    g = ora.table("ora_generator_affine", 1)[0]
+    G = (_t(g[:6]), _t(g[6:]))
+    neg = lambda q: (q[0], M.f6_neg(q[1]))
+    mshift = neg(M.scalar_mul(1 << 256, M.SHIFT_POINT))
+    pts = [M.scalar_mul(int(rng.integers(2, 2**62)), G) for _ in range(3)]
+    ks = [int.from_bytes(rng.bytes(32), "little") >> 1, 0x123456789abcdef0123, M.Q - 1]
+    arr = np.array([list(p[0]) + list(p[1]) for p in pts], np.uint64)
+    kb = np.stack([np.frombuffer(int(k).to_bytes(32, "little"), np.uint8) for k in ks])
+
+    def add(acc, base, d):
+        if d == 0:
+            return acc
+        q = M.scalar_mul(abs(d), base)
+        return hehcc_proj_add_mixed(acc, neg(q) if d < 0 else q)
+
+    for m in (2, 3):
+        acc = (M.SHIFT_POINT[0], M.SHIFT_POINT[1], M.ONE)
+        digits = [_radix16(k) for k in ks[:m]]
+        for i in range(63, -1, -1):
+            for _ in range(4):
+                acc = hehcc_proj_double(acc)
+            for j in range(m):
+                acc = add(acc, pts[j], digits[j][i])
+        acc = hehcc_proj_add_mixed(acc, mshift)
+        got, _ = ora.multiply_many_batch(arr[:m], AFFINE, kb[:m], m, PROJECTIVE, vartime=False)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], ("multiply_many", m)
+        acc = (M.SHIFT_POINT[0], M.SHIFT_POINT[1], M.ONE)
+        digits = [_wnaf(k, 5) for k in ks[:m]]
+        for i in range(255, -1, -1):
+            acc = hehcc_proj_double(acc)
+            for j in range(m):
+                acc = add(acc, pts[j], digits[j][i])
+        acc = hehcc_proj_add_mixed(acc, mshift)
+        got, _ = ora.multiply_many_batch(arr[:m], AFFINE, kb[:m], m, PROJECTIVE, vartime=True)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], ("multiply_many_vartime", m)
+    # a P + b G
+    acc = (M.SHIFT_POINT[0], M.SHIFT_POINT[1], M.ONE)
+    da, db = _wnaf(ks[0], 5), _wnaf(ks[1], 8)
+    for i in range(255, -1, -1):
+        acc = hehcc_proj_double(acc)
+        acc = add(acc, pts[0], da[i])
+        acc = add(acc, G, db[i])
+    acc = hehcc_proj_add_mixed(acc, mshift)
+    got, _ = ora.multiply_many_batch(arr[:1], AFFINE, kb[:2], 1, PROJECTIVE, vartime=True, with_basepoint=True)
+    assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], "multiply_double_with_basepoint_vartime"
