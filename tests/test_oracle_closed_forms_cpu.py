@@ -377,3 +377,32 @@ def test_multi_scalar_representatives_are_compositions_of_the_closed_forms(ora):
     acc = hehcc_proj_add_mixed(acc, mshift)
     got, _ = ora.multiply_many_batch(arr[:1], AFFINE, kb[:2], 1, PROJECTIVE, vartime=True, with_basepoint=True)
     assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], "multiply_double_with_basepoint_vartime"
+
+
+def test_basepoint_lookup_representative_is_a_composition_of_the_closed_forms(ora):
+    """&BASEPOINT_LOOKUP * &Scalar (src/constants.rs:102-135): signed radix-256 digits (src/scalar.rs:555-576), from S
+    eight doublings and one table entry d G per byte, then - 2^256 S, on the modified-Jacobian accumulator whose
+    (X, Y, Z) are the Jacobian formulas' -- the JacobianPoint it returns, from the closed forms."""
+    rng = np.random.default_rng(14)
+    g = ora.table("ora_generator_affine", 1)[0]
+    G = (_t(g[:6]), _t(g[6:]))
+    neg = lambda q: (q[0], M.f6_neg(q[1]))
+    mshift = neg(M.scalar_mul(1 << 256, M.SHIFT_POINT))
+    jac_add_mixed = lambda p, q: hehcc_add(p, (q[0], q[1], M.ONE))
+    for k in (1, 128, 0xff80, int.from_bytes(rng.bytes(32), "little") >> 1, M.Q - 1):
+        d = [(k >> (8 * i)) & 255 for i in range(32)]
+        for i in range(31):
+            carry = (d[i] + 128) >> 8
+            d[i] -= carry << 8
+            d[i + 1] += carry
+        acc = (M.SHIFT_POINT[0], M.SHIFT_POINT[1], M.ONE)
+        for i in range(31, -1, -1):
+            for _ in range(8):
+                acc = hehcc_double(acc)
+            if d[i]:
+                q = M.scalar_mul(abs(d[i]), G)
+                acc = jac_add_mixed(acc, neg(q) if d[i] < 0 else q)
+        acc = jac_add_mixed(acc, mshift)
+        kb = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8).reshape(1, 32)
+        got, _ = ora.mul_by_generator_batch(kb, JACOBIAN)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], k
