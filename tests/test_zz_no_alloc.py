@@ -73,3 +73,54 @@ def test_noalloc_entry_point_matches_the_allocating_one():
         assert lib.cheetah_multiply_batch_dev_noalloc(h, None, AFFINE, None, None, None, 0, AFFINE) == 0
     finally:
         lib.cheetah_ctx_destroy(h)
+
+
+def test_noalloc_entry_point_under_hip_graph_capture():
+    """The callers the entry point is for: its launches captured ONCE into a HIP graph (stream capture forbids
+    hipMalloc / hipFree / synchronisation, and the call makes none), the graph replayed twice -- the second time with
+    new scalars in the same buffers -- and both results equal to the allocating entry point's."""
+    import torch
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.cheetah_ctx_create((C.c_int * 1)(0), 1, C.byref(h)) == 0, lib.cheetah_last_error(None)
+    try:
+        n = 30000
+        r = torch.from_numpy(synth.scalars(75, n, 1 << 20)).cuda()
+        ks = torch.from_numpy(synth.scalars(75, n)).cuda()
+        pts = torch.empty((n, 12), dtype=torch.int64, device="cuda")
+        pinf = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        want = torch.empty((n, 12), dtype=torch.int64, device="cuda")
+        winf = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        out = torch.full((n, 12), -1, dtype=torch.int64, device="cuda")
+        inf = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert lib.cheetah_mul_by_generator_batch_dev(h, r.data_ptr(), pts.data_ptr(), pinf.data_ptr(), n, AFFINE) == 0
+        assert lib.cheetah_ctx_synchronize(h) == 0
+
+        def reference():
+            assert lib.cheetah_ctx_use_own_stream(h) == 0
+            assert lib.cheetah_multiply_batch_dev(h, pts.data_ptr(), AFFINE, ks.data_ptr(), want.data_ptr(), winf.data_ptr(), n, AFFINE) == 0
+            assert lib.cheetah_ctx_synchronize(h) == 0
+
+        reference()
+        s = torch.cuda.Stream()
+        assert lib.cheetah_ctx_set_stream(h, C.c_void_p(s.cuda_stream)) == 0
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            rc = lib.cheetah_multiply_batch_dev_noalloc(h, pts.data_ptr(), AFFINE, ks.data_ptr(), out.data_ptr(), inf.data_ptr(), n, AFFINE)
+        assert rc == 0, lib.cheetah_last_error(h)
+        torch.cuda.synchronize()
+        assert bool((out == -1).all()), "capture must record the launches, not run them"
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and torch.equal(inf, winf)
+        ks.copy_(torch.from_numpy(synth.scalars(76, n)).cuda())
+        torch.cuda.synchronize()
+        reference()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and torch.equal(inf, winf)
+        del g
+    finally:
+        lib.cheetah_ctx_destroy(h)
