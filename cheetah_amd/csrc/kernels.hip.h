@@ -1858,25 +1858,56 @@ __global__ void __launch_bounds__(BLOCK) k_affine_from_x(const u64* __restrict__
 // (x, +-sqrt) -- the reference's loop.  cheetah_random_points_dev then clears the cofactor (fixed-scalar ladder).
 // 36 attempts fit the 256 draws; an element that found none (probability 2^-36) leaves as the identity encoding (0, 1).
 constexpr int RANDOM_MAX_ATTEMPTS = 36;
+// Half of all x have no point over them, so a lane that retried on its own would hold its wave for the unluckiest of
+// its 64 elements (7 - 8 attempts, measured: this kernel was 60 % of cheetah_random_points_dev).  Instead the wave
+// shares the attempts out: every round its 64 lanes test attempts a .. a + per - 1 of each still unsolved element
+// (per = 64 / unsolved: 1, then ~ 2, ~ 8, ...), the LOWEST successful attempt of an element wins -- the same point the
+// sequential loop returns -- and a wave is done in 3 - 4 rounds.
 __global__ void __launch_bounds__(BLOCK) k_random_candidates(u64 seed, u64 start, u64* __restrict__ xy, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        Affine p = affine_identity();
-        const u64 base = (start + i) * 256ull;
-        for (int a = 0; a < RANDOM_MAX_ATTEMPTS; a++) {
+    __shared__ u8 s_item[BLOCK];
+    __shared__ int s_win[BLOCK];
+    const int t = threadIdx.x, lane = t & 63, wbase = t & ~63;
+    const size_t nround = (n + BLOCK - 1) / BLOCK;
+    for (size_t round = blockIdx.x; round < nround; round += gridDim.x) {
+        const size_t i0 = round * BLOCK + wbase;  // the wave's elements: i0 .. i0 + 63
+        u64 unsolved = __builtin_amdgcn_ballot_w64(i0 + lane < n);
+        int next = 0;  // every unsolved element has tried attempts [0, next); wave-uniform
+        while (unsolved != 0 && next < RANDOM_MAX_ATTEMPTS) {
+            const int cnt = __builtin_popcountll(unsolved);
+            int per = 64 / cnt;
+            if (per > RANDOM_MAX_ATTEMPTS - next) per = RANDOM_MAX_ATTEMPTS - next;
+            if ((unsolved >> lane) & 1ull) s_item[wbase + __builtin_popcountll(unsolved & ((1ull << lane) - 1ull))] = (u8)lane;
+            s_win[t] = RANDOM_MAX_ATTEMPTS;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int slot = lane / per, a = next + lane % per;  // this lane: attempt a of the slot-th unsolved element
+            const bool work = slot < cnt;
+            const int item = work ? (int)s_item[wbase + slot] : 0;
+            const u64 base = (start + i0 + (u64)item) * 256ull;
             Fp6 x;
 #pragma unroll
             for (int l = 0; l < 6; l++) x.c[l] = fp_canonical(splitmix64(seed, base + 7 * a + l));
             const bool flip = (u32)splitmix64(seed, base + 7 * a + 6) & 1u;
             bool ok;
             Fp6 y = fp6_sqrt(curve_rhs(x), &ok);
-            if (ok) {
-                p.x = x;
-                p.y = flip ? fp6_neg(y) : y;
-                break;
+            ok = ok && work;
+            if (ok) atomicMin(&s_win[wbase + item], a);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (ok && s_win[wbase + item] == a) {  // the first success of its element, as the sequential loop would find it
+                const size_t i = i0 + (size_t)item;
+                store_fp6_vec_canonical(xy + 12 * i, x);
+                store_fp6_vec_canonical(xy + 12 * i + 6, flip ? fp6_neg(y) : y);
             }
+            unsolved &= ~__builtin_amdgcn_ballot_w64(s_win[t] != RANDOM_MAX_ATTEMPTS);
+            next += per;
+            __builtin_amdgcn_wave_barrier();
         }
-        store_fp6_vec_canonical(xy + 12 * i, p.x);
-        store_fp6_vec_canonical(xy + 12 * i + 6, p.y);
+        if ((unsolved >> lane) & 1ull) {  // no square in 36 attempts (2^-36): the identity encoding
+            const size_t i = i0 + (size_t)lane;
+            store_fp6_vec_canonical(xy + 12 * i, fp6_zero());
+            store_fp6_vec_canonical(xy + 12 * i + 6, fp6_one());
+        }
     }
 }
 

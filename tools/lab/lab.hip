@@ -186,6 +186,14 @@ extern "C" int lab_multiply_w(int w, int direct, const DeviceTables* tab, const 
 extern "C" size_t lab_ct_scratch_words() { return (size_t)lab_num_cus() * CH_CT_WAVES * LaneScratch::WORDS_PER_BLOCK; }
 #endif
 
+#ifdef LAB_RAND
+extern "C" int lab_random_candidates(u64 seed, u64 start, u64* xy, size_t n, void* stream) {
+    size_t want = (n + BLOCK - 1) / BLOCK, cap = (size_t)lab_num_cus() * 8;
+    hipLaunchKernelGGL(k_random_candidates, dim3((int)(want < cap ? want : cap)), dim3(BLOCK), 0, (hipStream_t)stream, seed, start, xy, n);
+    return (int)hipGetLastError();
+}
+#endif
+
 // The reference's lazy_static tables (shift points, BASEPOINT_LOOKUP, ODD_MULTIPLES) for the kernels under test: built by
 // the product's own k_build_tables from the generator and the shift point (device pointers to 12 limbs each).
 extern "C" void* lab_build_tables(const u64* gen_xy, const u64* shift_xy) {
