@@ -56,6 +56,11 @@ struct DeviceTables {
     // Fixed-base table of k_mul_by_generator_wide (affine results only; no counterpart in the reference):
     // wide[j][e] = (e + 1) 64^j G, window-major, entry-major, x|y.
     u64 wide[43 * 32 * 12];
+    // double_unchecked^d(S) for d = 0 .. 256 in both accumulator types, the reference's own representatives: a ladder
+    // whose scalar is the same for the whole batch (clear_cofactor, is_torsion_free) starts at the first non-zero digit
+    // of its NAF with the accumulator the reference reaches there by doubling S alone.
+    u64 shift_dbl_proj[257 * 18];
+    u64 shift_dbl_mjac[257 * 24];
     // bit 0: cheetah_ctx_set_point_independent_tables -- the constant-time ladders build EVERY wave's window tables with
     // the reference's complete additions (no wave-level choice that depends on the points)
     u64 flags;
@@ -149,6 +154,7 @@ template <class ACC> struct Ladder;
 template <> struct Ladder<Proj> {
     static CH_DEV Proj from_affine(const Affine& a) { return proj_from_affine(a); }
     static CH_DEV Proj shift16(const DeviceTables* tab) { return load_proj(tab->shift16_proj); }
+    static CH_DEV Proj shift_doubled(const DeviceTables* tab, int d) { return load_proj(tab->shift_dbl_proj + 18 * d); }
     static CH_DEV Proj dbl_inl(const Proj& p) { return proj_double_unchecked_impl<true>(p); }  // field products inlined
     static CH_DEV Proj add(const Proj& p, const Affine& q) { return proj_add_mixed_unchecked(p, q); }
     static CH_DEV Proj dbls_then_add(const Proj& p, int n) { return proj_doubles_unchecked(p, n); }
@@ -164,6 +170,15 @@ template <> struct Ladder<MJac> {
         m.y = load_fp6(tab->shift16_mjac + 6);
         m.z = load_fp6(tab->shift16_mjac + 12);
         m.z4 = load_fp6(tab->shift16_mjac + 18);
+        return m;
+    }
+    static CH_DEV MJac shift_doubled(const DeviceTables* tab, int d) {
+        const u64* o = tab->shift_dbl_mjac + 24 * d;
+        MJac m;
+        m.x = load_fp6(o);
+        m.y = load_fp6(o + 6);
+        m.z = load_fp6(o + 12);
+        m.z4 = load_fp6(o + 18);
         return m;
     }
     static CH_DEV MJac dbl_inl(const MJac& p) { return mjac_double_impl<true, true>(p); }
@@ -267,6 +282,23 @@ __global__ void __launch_bounds__(BUILD_TABLES_THREADS) k_build_tables(DeviceTab
         store_fp6_canonical(tab->shift16_mjac + 6, m.y);
         store_fp6_canonical(tab->shift16_mjac + 12, m.z);
         store_fp6_canonical(tab->shift16_mjac + 18, m.z4);
+    } else if (t == 34 || t == 35) {
+        const Affine s = load_affine(shift_xy);
+        Proj p = proj_from_affine(s);
+        MJac m = mjac_from_affine(s);
+        for (int d = 0; d <= 256; d++) {
+            if (t == 34) {
+                store_proj(tab->shift_dbl_proj, nullptr, (size_t)d, p);
+                p = proj_double_unchecked(p);
+            } else {
+                u64* o = tab->shift_dbl_mjac + 24 * d;
+                store_fp6_canonical(o, m.x);
+                store_fp6_canonical(o + 6, m.y);
+                store_fp6_canonical(o + 12, m.z);
+                store_fp6_canonical(o + 18, m.z4);
+                m = mjac_double_unchecked(m);
+            }
+        }
     } else if (t >= 64) {
         const bool odd = t >= 192;
         const int m = odd ? 2 * (t - 192) + 1 : t - 63;  // multiplier, by left-to-right double-and-add with the complete formulas
@@ -1193,6 +1225,13 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
         // phases per wave instead of 256 + 256 for a lock-step loop.
         int pos = 255;       // next digit position of this lane
         int pd = 0;          // parked digit
+        if (uniform_scalar) {
+            // one scalar for the whole batch: the doublings before its first non-zero digit act on S alone, and what
+            // they produce is a constant of the context (DeviceTables::shift_dbl_*, the same formulas, the same
+            // representative) -- clear_cofactor's 130-bit h skips 125 of its 256 doublings
+            while (pos >= 0 && naf4_digit(s_naf, pos, t) == 0) pos--;
+            acc = Ladder<ACC>::shift_doubled(tab, 255 - pos);
+        }
         for (;;) {
             const bool can = pd == 0 && pos >= 0;
             const u64 m_can = __builtin_amdgcn_ballot_w64(can);
