@@ -34,6 +34,10 @@ constexpr int BLOCK = 256;
 // calls instead of inlined are 1 - 3 % slower: what bounds these kernels is the number of resident waves.
 #define CH_MANY_WAVES 3
 #endif
+// NafLookupTable<8> by shared-inversion affine steps (1) or always by the reference's construction (0)
+#ifndef CH_NAF_TABLE_AFFINE
+#define CH_NAF_TABLE_AFFINE 1
+#endif
 #ifndef CH_BN_WAVES
 #define CH_BN_WAVES 3
 #endif
@@ -1093,6 +1097,86 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
     return 0u;
 }
 
+// NafLookupTable<8>::from (src/naf_lookup.rs:35-48): the odd multiples P, 3P, ..., 15P as affine points, by the same
+// shared-inversion affine steps.  With E = 2P, 4P, 8P in turn: (2 have + 2i + 1) P = E + (2i + 1) P for the `have` odd
+// multiples already there, and the next E = 2 E, one inversion per level: 4 inversions + 10 chord / tangent steps +
+// Montgomery's trick (~ 42 k instructions) instead of a doubling, 7 complete additions and a normalisation (~ 64 k).
+// Every exceptional case (the identity, a point of order <= 15) makes a denominator zero; the caller then rebuilds
+// the wave's tables with the reference's construction, as it does for a point that is not on the curve.
+CH_DEV bool build_naf_table_affine(const Affine& P, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
+    bool bad = P.inf;
+    sc_store(s_tab, 0, 0, P.x, t, 12);
+    sc_store(s_tab, 0, 6, P.y, t, 12);
+    auto tangent = [](const Affine& e, const Fp6& inv) {  // 2 e, inv = 1 / (2 y)
+        Fp6 num = fp6_triple(fp6_square(e.x));
+        num.c[0] = fp_add(num.c[0], 1ull);  // 3 x^2 + a, a = 1
+        const Fp6 lam = fp6_mul(num, inv);
+        Affine r;
+        r.x = fp6_sub(fp6_square(lam), fp6_double(e.x));
+        r.y = fp6_sub(fp6_mul(lam, fp6_sub(e.x, r.x)), e.y);
+        r.inf = false;
+        return r;
+    };
+    bool some;
+    Affine E = tangent(P, fp6_invert(fp6_double(P.y), &some));
+    bad = bad || !some;
+    for (int have = 1; have < 8; have *= 2) {
+        const int nd = have + (have < 4 ? 1 : 0);  // the chords' denominators x_E - x_i, then the tangent's 2 y_E
+        Fp6 acc = fp6_one();
+        for (int i = 0; i < nd; i++) {
+            const Fp6 d = i < have ? fp6_sub(E.x, sc_load(s_tab, i, 0, t, 12)) : fp6_double(E.y);
+            sc_store(s_z, i, 0, d, t, 6);
+            if (i == 0) {
+                acc = d;
+            } else {
+                sc_store(s_prefix, i, 0, acc, t, 6);
+                acc = fp6_mul(acc, d);
+            }
+        }
+        acc = fp6_invert(acc, &some);
+        bad = bad || !some;
+        Affine next = E;
+        for (int i = nd - 1; i >= 0; i--) {
+            Fp6 inv = acc;  // 1 / d_i
+            if (i > 0) {
+                inv = fp6_mul(sc_load(s_prefix, i, 0, t, 6), acc);
+                acc = fp6_mul(acc, sc_load(s_z, i, 0, t, 6));
+            }
+            if (i < have) {
+                const Fp6 xa = sc_load(s_tab, i, 0, t, 12), ya = sc_load(s_tab, i, 6, t, 12);
+                const Fp6 lam = fp6_mul(fp6_sub(E.y, ya), inv);
+                const Fp6 x3 = fp6_sub(fp6_sub(fp6_square(lam), xa), E.x);
+                sc_store(s_tab, have + i, 0, x3, t, 12);
+                sc_store(s_tab, have + i, 6, fp6_sub(fp6_mul(lam, fp6_sub(xa, x3)), ya), t, 12);
+            } else {
+                next = tangent(E, inv);
+            }
+        }
+        E = next;
+    }
+    return !bad;
+}
+
+// NafLookupTable<8>::from for the lane's input point; returns the identity mask of the entries (as build_table).
+template <int IN_FORM>
+CH_DEV u32 build_naf_lookup_table(const u64* pts, size_t i, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
+#if CH_NAF_TABLE_AFFINE
+    Affine pa;
+    if (IN_FORM == 1) {
+        pa = affine_from_proj(load_proj(pts + 18 * i));
+    } else {
+        const Proj p = load_input_point<IN_FORM>(pts, i);
+        pa.x = p.x;
+        pa.y = p.y;
+        pa.inf = fp6_is_zero(p.z);
+    }
+    bool ok = !pa.inf && affine_on_curve(pa.x, pa.y);
+    ok = build_naf_table_affine(pa, s_tab, s_z, s_prefix, t) && ok;
+    if (!__any(!ok)) return 0u;
+#endif
+    return build_table<true>(load_input_point<IN_FORM>(pts, i), 8, s_tab, s_z, s_prefix, t);
+}
+
 // Constant-time lookup (src/lookup.rs:81-102): read every entry, keep entry |d|.
 CH_DEV Affine scan_lookup(const u64* s_tab, int n_entries, u32 ident, int d, int t) {
     const int neg = d < 0;
@@ -1213,8 +1297,7 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
         recode_wnaf5_packed(k, s_naf, t);
         __syncthreads();
         if (ONLY_WIDE && !__any(redo)) continue;
-        const Proj p = load_input_point<IN_FORM>(pts, ii);
-        const u32 ident = build_table<true>(p, 8, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_naf_lookup_table<IN_FORM>(pts, ii, s_tab, s_z, s_prefix, t);
         ACC acc = Ladder<ACC>::from_affine(shift);
         // Every lane runs ITS OWN reference sequence (256 doublings, an addition after
         // each non-zero digit), so the representative it ends with is the reference's.
@@ -1387,8 +1470,7 @@ __global__ void __launch_bounds__(BLOCK, CH_VT_POOL_WAVES) k_multiply_vartime_po
             s_pos[s * BLOCK + t] = active ? (short)255 : (short)-1;
             s_pd[s * BLOCK + t] = 0;
             if (__any(active)) {
-                const Proj p = load_input_point<IN_FORM>(pts, ii);
-                s_ident[s * BLOCK + t] = (u8)build_table<true>(p, 8, base + s * VtPool::TAB, s_z, s_prefix, t);
+                s_ident[s * BLOCK + t] = (u8)build_naf_lookup_table<IN_FORM>(pts, ii, base + s * VtPool::TAB, s_z, s_prefix, t);
                 AccIO<ACC>::store(state0 + (size_t)s * NF * 6 * BLOCK, Ladder<ACC>::from_affine(shift), t);
             }
         }
@@ -1606,8 +1688,7 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
             recode_wnaf(k, j < m ? 5 : 8, s_dig + (size_t)j * 256 * BLOCK, t);
         }
         for (int j = 0; j < m; j++) {
-            const Proj p = load_input_point<IN_FORM>(pts, gg * m + j);
-            s_ident[j * BLOCK + t] = build_table<true>(p, 8, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
+            s_ident[j * BLOCK + t] = build_naf_lookup_table<IN_FORM>(pts, gg * m + j, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t);
         }
         ACC acc = Ladder<ACC>::from_affine(shift);
         // Same wave-level parking as k_multiply_vartime; a lane may now owe several
