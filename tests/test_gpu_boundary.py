@@ -398,9 +398,21 @@ def test_multiply_low_order_points_fall_back_to_the_complete_formulas(eng, ora, 
         prj[i, 12:] = 0
     for arr, form in ((jac, JACOBIAN), (prj, PROJECTIVE)):
         for out_form in (AFFINE, form):
-            want, winf = ora.multiply_batch(arr, form, k, out_form)
-            got, ginf = eng.multiply_batch(dev(arr), dev(k), form, out_form)
-            assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, out_form)
+            for vt in (False, True):          # vartime: NafLookupTable<8> by affine steps, the same fallback
+                want, winf = ora.multiply_batch(arr, form, k, out_form, vartime=vt)
+                f = eng.multiply_vartime_batch if vt else eng.multiply_batch
+                got, ginf = f(dev(arr), dev(k), form, out_form)
+                assert (host(got) == want).all() and (host(ginf) == winf).all(), (form, out_form, vt)
+    # the uniform-scalar ladders and the Straus NAF ladder over the same points
+    hb = np.repeat(sc(h), n, axis=0)
+    want, winf = ora.multiply_batch(pts, 0, hb, PROJECTIVE, vartime=True)
+    got, ginf = eng.clear_cofactor_batch(dev(pts), AFFINE, PROJECTIVE)
+    assert (host(got) == want).all() and (host(ginf) == winf).all()
+    want = ora.multiply_batch(pts, 0, np.repeat(sc(synth.Q), n, axis=0), JACOBIAN, vartime=True)[1]
+    assert (host(eng.is_torsion_free_batch(dev(pts), AFFINE)) == want).all()   # whatever the reference's incomplete formulas make of them
+    want, winf = ora.multiply_many_batch(pts, 0, k, 2, PROJECTIVE, vartime=True)
+    got, ginf = eng.multiply_many_vartime_batch(dev(pts), dev(k), 2, AFFINE, PROJECTIVE)
+    assert (host(got) == want).all() and (host(ginf) == winf).all()
 
 
 # ------------------------------------------- off-curve inputs (window-table fallback) -----

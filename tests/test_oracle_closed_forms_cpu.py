@@ -190,7 +190,7 @@ def _wnaf5(k):
     return d[:256]
 
 
-def _ladder(pt, k, vartime, dbl, add_mixed):
+def _ladder(pt, k, vartime, dbl, add_mixed, entry_fn=None):
     """{Projective,Jacobian}Point::multiply / multiply_vartime as the reference composes them (src/curve/projective.rs:
     614-662, src/curve/jacobian.rs:599-649): from the shift point S, doublings and mixed additions of table entries,
     then - 2^256 S (multiply_vartime too: its "skip unset digits" loop never moves off 255).  The table entries are
@@ -202,13 +202,15 @@ def _ladder(pt, k, vartime, dbl, add_mixed):
 
     def entry(j):
         if j not in table:
-            table[j] = M.scalar_mul(j, pt)
+            table[j] = entry_fn(j) if entry_fn else M.scalar_mul(j, pt)
         return table[j]
 
     def add(acc, d):
         if d == 0:
             return acc                                   # the identity operand: add_mixed_unchecked returns self
         q = entry(abs(d))
+        if q is None:
+            return acc                                   # an identity in the table: add_mixed_unchecked returns self
         return add_mixed(acc, neg(q) if d < 0 else q)
 
     if vartime:
@@ -406,3 +408,37 @@ def test_basepoint_lookup_representative_is_a_composition_of_the_closed_forms(or
         kb = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8).reshape(1, 32)
         got, _ = ora.mul_by_generator_batch(kb, JACOBIAN)
         assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [acc[0], acc[1], acc[2]], k
+
+
+def test_quirk_the_complete_formulas_are_not_complete_on_this_curve(ora):
+    """Quirk Q7 (reference behaviour, reproduced by the oracle and the GPU).  RCB15's addition is complete on curves
+    WITHOUT a point of order 2; Cheetah's cofactor is even, and for its 2-torsion point T (y = 0) the pair (O, T) is
+    exceptional: `double(T) + T` -- the step that fills NafLookupTable / LookupTable (src/naf_lookup.rs:35-48,
+    src/lookup.rs:25-37) -- evaluates to (0, 0, 0), which batch_normalize stores as the identity.  So the reference's
+    table of T is [T, O, O, ...] instead of [T, T, T, ...], 3 T comes out as the identity, and is_torsion_free
+    (multiply_vartime by q, src/curve/projective.rs:885-893) answers from the scalar's +-1 digits alone.  Shown here on
+    the closed forms; the oracle's ladders equal the composition over that table, not over the true multiples."""
+    import json
+    import os
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))
+    v = kats["non_subgroup_point"]
+    n_pt = np.array([v["x"] + v["y"]], np.uint64)
+    h = int.from_bytes(bytes(kats["cofactor_bytes"]), "little")
+    sc = lambda x: np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).reshape(1, 32).copy()
+    qn, _ = ora.multiply_batch(n_pt, AFFINE, sc(M.Q), AFFINE, vartime=True)
+    t2, tinf = ora.multiply_batch(qn, AFFINE, sc(h // 2), AFFINE, vartime=True)
+    assert tinf[0] == 0 and (t2[0, 6:] == 0).all()                       # the point of order 2: y = 0
+    T = (_t(t2[0, :6]), _t(t2[0, 6:]))
+    assert M.is_on_curve(T) and M.scalar_mul(2, T) is None
+    dbl = hehcc_proj_double((T[0], T[1], M.ONE))
+    assert dbl[0] == M.ZERO and dbl[1] != M.ZERO and dbl[2] == M.ZERO    # an identity, (0 : Y : 0)
+    assert rcb_add(dbl, (T[0], T[1], M.ONE)) == (M.ZERO, M.ZERO, M.ZERO)  # O + T by the "complete" formula
+    quirk_table = lambda j: T if j == 1 else None
+    jac_add_mixed = lambda p, q: hehcc_add(p, (q[0], q[1], M.ONE))
+    for k in (1, 3, 5, 0x21, 0xabcdef, M.Q):
+        want = _ladder(T, k, True, hehcc_double, jac_add_mixed, entry_fn=quirk_table)
+        got, inf = ora.multiply_batch(t2, AFFINE, sc(k), JACOBIAN, vartime=True)
+        assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [want[0], want[1], want[2]], k
+        assert inf[0] == (1 if want[2] == M.ZERO else 0)
+    got, inf = ora.multiply_batch(t2, AFFINE, sc(3), JACOBIAN, vartime=True)
+    assert inf[0] == 1                                                   # "3 T = O"
