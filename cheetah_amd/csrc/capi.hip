@@ -67,6 +67,7 @@ struct cheetah_ctx {
     // multi-device: the caller's context is shard 0 and owns one sub-context per further device
     std::vector<cheetah_ctx*> subs;
     DevSlot pair_tmp;           // multiply_double_with_basepoint_vartime, affine results: split scalars and the two partial points
+    DevSlot redo_flags;         // vartime fast paths: one byte per wave of a launch, set for the waves left to the NAF kernels
     std::vector<DevSlot> peer;  // a sub-context's staging for `_dev` calls (its shard of the caller's device arrays)
     hipEvent_t ev_peer = nullptr;
     std::string err;
@@ -140,6 +141,7 @@ static void destroy_one(cheetah_ctx* ctx) {
     for (auto& d : ctx->peer)
         if (d.p) (void)hipFree(d.p);
     if (ctx->pair_tmp.p) (void)hipFree(ctx->pair_tmp.p);
+    if (ctx->redo_flags.p) (void)hipFree(ctx->redo_flags.p);
     hipEvent_t evs[] = {ctx->ev0, ctx->ev1, ctx->ev_order, ctx->ev_peer, ctx->ev_in[0], ctx->ev_in[1],
                         ctx->ev_k[0], ctx->ev_k[1], ctx->ev_out[0], ctx->ev_out[1]};
     for (hipEvent_t e : evs)
@@ -1035,9 +1037,11 @@ extern "C" int32_t cheetah_mul_by_generator_batch(cheetah_ctx* ctx, const uint8_
 struct cheetah_basepoint_table {
     cheetah_ctx* ctx = nullptr;
     std::vector<u64*> comb, wide;  // one copy per shard of the context
-    // A base that is NOT on the curve (an unchecked decoding can produce one): the reference's comb still returns a
-    // definite value for it, but the widened comb -- another schedule over other multiples -- returns another, so AFFINE
-    // results then come from the reference's comb and a normalisation (k_mul_by_generator<0, GENERIC>).
+    // A base that is NOT on the curve (an unchecked decoding can produce one), or one of small order / whose reference
+    // table met the complete addition's exceptional pair (quirk Q7: an identity or a y = 0 among the comb's entries): the
+    // reference's comb still returns a definite value for it, but the widened comb -- another schedule over other
+    // multiples -- returns another, so AFFINE results then come from the reference's comb and a normalisation
+    // (k_mul_by_generator<0, GENERIC>).  false in either case.
     bool on_curve = true;
 };
 constexpr size_t COMB_WORDS = 32 * 8 * 12, WIDE_WORDS = (size_t)WIDE_WINDOWS * WIDE_ENTRIES * 12;
@@ -1088,11 +1092,12 @@ extern "C" int32_t cheetah_basepoint_table_create(cheetah_ctx* ctx, const uint64
                 u8* flag = reinterpret_cast<u8*>(pt + 20);
                 if (in_form == CHEETAH_AFFINE) hipLaunchKernelGGL((k_is_on_curve<0>), dim3(1), dim3(BLOCK), 0, c->stream, pt, flag, (size_t)1);
                 else hipLaunchKernelGGL((k_is_on_curve<1>), dim3(1), dim3(BLOCK), 0, c->stream, pt, flag, (size_t)1);
+                hipLaunchKernelGGL(k_comb_table_is_ordinary, dim3(1), dim3(256), 0, c->stream, t->comb[i], flag + 1);
                 e = hipGetLastError();
-                u8 on = 1;
-                if (e == hipSuccess) e = hipMemcpyAsync(&on, flag, 1, hipMemcpyDeviceToHost, c->stream);
+                u8 on[2] = {1, 1};  // on the curve; no identity and no y = 0 among the comb's 256 entries
+                if (e == hipSuccess) e = hipMemcpyAsync(on, flag, 2, hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                if (e == hipSuccess && !on) t->on_curve = false;
+                if (e == hipSuccess && !(on[0] && on[1])) t->on_curve = false;
             }
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `point` is the caller's: done with it on return
         }
@@ -1183,6 +1188,11 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
     // more than it costs the lock-step ladders: measured at 2^22, projective representative, 20.6 M/s at 2 rounds per launch,
     // 21.7 at 16 (profiles/r03_ladder_timings.txt).  Its launches therefore cover POOL_ROUNDS_FACTOR times as many rounds.
     const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds * (pooled ? VtPool::SLOTS * POOL_ROUNDS_FACTOR : 1);
+    u8* flags = nullptr;  // the fast path's verdict per wave of a launch, read by the NAF kernel that follows it
+    if (direct) {
+        if (int32_t rc = ensure_slot(ctx, ctx->redo_flags, ((size_t)1 << 16) > per_launch / 64 + 1 ? ((size_t)1 << 16) : per_launch / 64 + 1, ctx->stream)) return rc;
+        flags = static_cast<u8*>(ctx->redo_flags.p);
+    }
     for (size_t off = 0; off < n; off += per_launch) {
         const size_t cnt = n - off < per_launch ? n - off : per_launch;
         const u64* pts_o = pts + off * in_w;
@@ -1193,9 +1203,9 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
     do {                                                                                                                       \
         if constexpr (VARTIME && O == 0) {                                                                                     \
             hipLaunchKernelGGL((k_multiply_ct<A, I, O, true>), dim3(grid_ct), dim3(BLOCK), 0, ctx->stream, ctx->tables, pts_o,  \
-                               sc_o, out_o, inf_o, cnt, arena);                                                                \
+                               sc_o, out_o, inf_o, cnt, arena, flags);                                                         \
             hipLaunchKernelGGL((k_multiply_vartime<A, I, O, true>), dim3(grid_vt), dim3(BLOCK), 0, ctx->stream, ctx->tables,    \
-                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0);                                                      \
+                               pts_o, sc_o, out_o, inf_o, cnt, arena, 0, flags);                                               \
         } else if constexpr (VARTIME)                                                                                          \
             hipLaunchKernelGGL((k_multiply_vartime_pool<A, I, O>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,        \
                                pts_o, sc_o, out_o, inf_o, cnt, arena, pool_words);                                             \
@@ -1328,6 +1338,11 @@ static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form,
     size_t rounds = (size_t)ctx->launch_rounds / (size_t)m;
     if (rounds == 0) rounds = 1;
     const size_t per_launch = (size_t)grid * BLOCK * rounds;
+    u8* flags = nullptr;
+    if (VARTIME && out_form == CHEETAH_AFFINE && !with_basepoint && !ctx->force_reference_schedule) {
+        if (int32_t rc = ensure_slot(ctx, ctx->redo_flags, ((size_t)1 << 16) > per_launch / 64 + 1 ? ((size_t)1 << 16) : per_launch / 64 + 1, ctx->stream)) return rc;
+        flags = static_cast<u8*>(ctx->redo_flags.p);
+    }
     for (size_t off = 0; off < n_groups; off += per_launch) {
         const size_t cnt = n_groups - off < per_launch ? n_groups - off : per_launch;
         const u64* pts_o = pts + off * m * in_w;
@@ -1339,9 +1354,9 @@ static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form,
         if constexpr (VARTIME && O == 0) {                                                                                        \
             if (!with_basepoint && !ctx->force_reference_schedule) { /* affine results: indexed fixed-window ladder + fix-up */    \
                 hipLaunchKernelGGL((k_multiply_many_ct<MJac, I, 0, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->tables,   \
-                                   pts_o, sc_o, out_o, inf_o, cnt, m, ctx->scratch, wpb);                                         \
+                                   pts_o, sc_o, out_o, inf_o, cnt, m, ctx->scratch, wpb, flags);                                  \
                 hipLaunchKernelGGL((k_multiply_many_vartime<MJac, I, 0, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream,           \
-                                   ctx->tables, pts_o, sc_o, out_o, inf_o, cnt, m, 0, ctx->scratch, wpb);                         \
+                                   ctx->tables, pts_o, sc_o, out_o, inf_o, cnt, m, 0, ctx->scratch, wpb, flags);                  \
                 break;                                                                                                            \
             }                                                                                                                     \
         }                                                                                                                         \

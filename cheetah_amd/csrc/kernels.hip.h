@@ -336,6 +336,16 @@ __global__ void __launch_bounds__(64) k_build_comb_table(u64* comb /* [32][8][12
     }
 }
 
+// flag[0] = 1 iff no entry of a comb table is the identity or has y = 0.  Such an entry means that the base has small
+// order or that the reference's chain of complete additions met its exceptional pair (quirk Q7): the reference's table
+// is then NOT the table of true multiples, and the widened comb, built from true multiples, must not stand in for it.
+__global__ void __launch_bounds__(256) k_comb_table_is_ordinary(const u64* __restrict__ comb /* [256][12] */, u8* __restrict__ flag) {
+    const Affine a = load_affine(comb + 12 * threadIdx.x);
+    const int odd = (int)affine_is_identity_encoding(a.x, a.y) | (int)fp6_is_zero(a.y);
+    const int any = __syncthreads_or(odd);
+    if (threadIdx.x == 0) flag[0] = any ? 0 : 1;
+}
+
 // ---------------------------------------------------------------------------
 // Elementwise Fp6 kernels (config 1): HBM-bound, 144 B per multiplication.
 // An element is 48 contiguous bytes = three 16-byte words; lane i of a wave reads
@@ -1006,8 +1016,14 @@ CH_DEV u32 build_table(const Proj& p, int n_entries, u64* s_tab, u64* s_z, u64* 
 // case (P the identity, or of order <= N: a doubling of a 2-torsion point, an addition of equal or opposite points)
 // makes a denominator zero, hence the level's product zero and its inversion `none`: the function then returns false
 // and the caller rebuilds that wave's tables with the reference's complete formulas (build_table).
+// One more case has to go there although no denominator vanishes (quirk Q7): the reference fills its table with the
+// Renes-Costello-Batina addition, which on THIS curve (even cofactor) has an exceptional pair whenever the difference of
+// its operands is the point of order 2 -- it then returns (0, 0, 0), stored as the identity.  In the chain
+// (i + 1) P = P + i P that happens iff some multiple m P, m < N, has y = 0 (P of order 2 or 10: the only even orders
+// below 2 N that divide the cofactor), so a multiple with y = 0 anywhere in the table sends the wave to the reference's
+// construction, which reproduces what the reference returns for such a point.
 CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
-    bool bad = P.inf;
+    bool bad = P.inf | fp6_is_zero(P.y);
     sc_store(s_tab, 0, 0, P.x, t, 12);
     sc_store(s_tab, 0, 6, P.y, t, 12);
     for (int lo = 1; lo < n_entries; lo *= 2) {
@@ -1055,6 +1071,7 @@ CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* 
             }
             sc_store(s_tab, m - 1, 0, x3, t, 12);
             sc_store(s_tab, m - 1, 6, y3, t, 12);
+            bad = bad | fp6_is_zero(y3);
         }
     }
     return !bad;
@@ -1068,9 +1085,12 @@ CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* 
 // arbitrary values: the reference's multiply() really returns those (and so does the constant-time path here), while
 // its multiply_vartime() returns the identity -- every entry of its NafLookupTable stays at z = 0.  With NAF_IDENTITY
 // such an input is replaced by (0, 1, 0), whose table is all identities, so the fast path agrees with the NAF ladder.
+// wave_unfit (the vartime fast paths): set instead of rebuilding when the wave holds a point the affine construction
+// refuses -- for such a point the reference's multiply_vartime is its NAF ladder over its NafLookupTable, which no
+// LookupTable reproduces, so the caller leaves the wave to the NAF kernel.
 template <int IN_FORM, bool NAF_IDENTITY = false>
 CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t,
-                              bool reference_only = false) {
+                              bool reference_only = false, bool* wave_unfit = nullptr) {
     Affine pa;
     if (IN_FORM == 1) {
         pa = affine_from_proj(load_proj(pts + 18 * i));
@@ -1090,6 +1110,10 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
         ok = build_table_affine(pa, n_entries, s_tab, s_z, s_prefix, t) && ok;
     }
     if (__any(!ok)) {
+        if (wave_unfit) {
+            *wave_unfit = true;
+            return 0u;
+        }
         Proj p = load_input_point<IN_FORM>(pts, i);
         if (IN_FORM == 1 && NAF_IDENTITY && fp6_is_zero(p.z)) p = proj_identity();
         return build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
@@ -1102,9 +1126,11 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
 // multiples already there, and the next E = 2 E, one inversion per level: 4 inversions + 10 chord / tangent steps +
 // Montgomery's trick (~ 42 k instructions) instead of a doubling, 7 complete additions and a normalisation (~ 64 k).
 // Every exceptional case (the identity, a point of order <= 15) makes a denominator zero; the caller then rebuilds
-// the wave's tables with the reference's construction, as it does for a point that is not on the curve.
+// the wave's tables with the reference's construction, as it does for a point that is not on the curve -- and for a
+// point with a multiple of y = 0 among the ones computed here (quirk Q7, see build_table_affine: the reference's chain
+// (2i + 1) P = 2 P + (2i - 1) P meets its formula's exceptional pair iff (2i - 3) P is the point of order 2).
 CH_DEV bool build_naf_table_affine(const Affine& P, u64* s_tab, u64* s_z, u64* s_prefix, int t) {
-    bool bad = P.inf;
+    bool bad = P.inf | fp6_is_zero(P.y);
     sc_store(s_tab, 0, 0, P.x, t, 12);
     sc_store(s_tab, 0, 6, P.y, t, 12);
     auto tangent = [](const Affine& e, const Fp6& inv) {  // 2 e, inv = 1 / (2 y)
@@ -1119,7 +1145,7 @@ CH_DEV bool build_naf_table_affine(const Affine& P, u64* s_tab, u64* s_z, u64* s
     };
     bool some;
     Affine E = tangent(P, fp6_invert(fp6_double(P.y), &some));
-    bad = bad || !some;
+    bad = bad | !some | fp6_is_zero(E.y);
     for (int have = 1; have < 8; have *= 2) {
         const int nd = have + (have < 4 ? 1 : 0);  // the chords' denominators x_E - x_i, then the tangent's 2 y_E
         Fp6 acc = fp6_one();
@@ -1146,13 +1172,16 @@ CH_DEV bool build_naf_table_affine(const Affine& P, u64* s_tab, u64* s_z, u64* s
                 const Fp6 xa = sc_load(s_tab, i, 0, t, 12), ya = sc_load(s_tab, i, 6, t, 12);
                 const Fp6 lam = fp6_mul(fp6_sub(E.y, ya), inv);
                 const Fp6 x3 = fp6_sub(fp6_sub(fp6_square(lam), xa), E.x);
+                const Fp6 y3 = fp6_sub(fp6_mul(lam, fp6_sub(xa, x3)), ya);
                 sc_store(s_tab, have + i, 0, x3, t, 12);
-                sc_store(s_tab, have + i, 6, fp6_sub(fp6_mul(lam, fp6_sub(xa, x3)), ya), t, 12);
+                sc_store(s_tab, have + i, 6, y3, t, 12);
+                bad = bad | fp6_is_zero(y3);
             } else {
                 next = tangent(E, inv);
             }
         }
         E = next;
+        bad = bad | fp6_is_zero(E.y);
     }
     return !bad;
 }
@@ -1234,7 +1263,8 @@ CH_DEV ACC ladder_radix16(const DeviceTables* tab, const u64* s_tab, int n_entri
 template <class ACC, int IN_FORM, int OUT_FORM, bool DIRECT = false>
 __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                        const u8* __restrict__ scalars, u64* __restrict__ out,
-                                                       u8* __restrict__ inf, size_t n, u64* __restrict__ scratch) {
+                                                       u8* __restrict__ inf, size_t n, u64* __restrict__ scratch,
+                                                       u8* __restrict__ redo_flags = nullptr /* DIRECT: one byte per wave of 64 items */) {
     __shared__ i8 s_digits[64 * BLOCK];
     const int t = threadIdx.x;
     u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
@@ -1254,11 +1284,22 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
         // canonical scalars (< 2^255) only ever select entries 1..8; a wave builds
         // all 16 entries of LookupTable<16> only if one of its lanes needs them
         const bool wide = (k[3] >> 60) > 7;
-        // DIRECT: a wave that holds a scalar with bit 255 set, or a point that is not on the curve (for which the two
-        // ladders, fed by different tables, disagree), belongs to the NAF kernel (ONLY_WIDE, the same predicate)
-        if (DIRECT && __any((int)(k[3] >> 63) | (int)!point_on_curve<IN_FORM>(pts, ii))) continue;
         const int n_entries = __any(wide) ? 16 : 8;
-        const u32 ident = build_lookup_table<IN_FORM, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, !DIRECT && (tab->flags & 1));
+        u32 ident;
+        if (DIRECT) {
+            // A wave that holds a scalar with bit 255 set (the NAF recoding truncates there), or a point the affine table
+            // construction refuses (the identity, small order, off the curve, quirk Q7: for those the reference's answer
+            // depends on ITS schedule and ITS table), belongs to the NAF kernel: recorded in redo_flags, which
+            // k_multiply_vartime<..., ONLY_WIDE> reads.
+            bool unfit = __any((int)(k[3] >> 63));
+            ident = 0;
+            if (!unfit) ident = build_lookup_table<IN_FORM, true>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, false, &unfit);
+            const size_t first = round * BLOCK + (size_t)(t & ~63);  // the wave's first item
+            if ((t & 63) == 0 && redo_flags != nullptr && first < n) redo_flags[first >> 6] = unfit ? 1 : 0;
+            if (unfit) continue;
+        } else {
+            ident = build_lookup_table<IN_FORM, false>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, (tab->flags & 1) != 0);
+        }
         const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
     }
@@ -1275,7 +1316,8 @@ template <class ACC, int IN_FORM, int OUT_FORM, bool ONLY_WIDE = false>
 __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply_vartime(const DeviceTables* __restrict__ tab,
                                                             const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                             u64* __restrict__ out, u8* __restrict__ inf, size_t n,
-                                                            u64* __restrict__ scratch, int uniform_scalar) {
+                                                            u64* __restrict__ scratch, int uniform_scalar,
+                                                            const u8* __restrict__ redo_flags = nullptr /* ONLY_WIDE */) {
     __shared__ u8 s_naf[64 * BLOCK];
     const int t = threadIdx.x;
     u64* s_tab = scratch + (size_t)blockIdx.x * LaneScratch::WORDS_PER_BLOCK;
@@ -1290,8 +1332,11 @@ __global__ void __launch_bounds__(BLOCK, ONLY_WIDE ? 2 : CH_VT_WAVES) k_multiply
         const size_t ii = active ? i : n - 1;
         u64 k[4];
         load_scalar(scalars, uniform_scalar ? 0 : ii, k);  // uniform: is_torsion_free / clear_cofactor (one fixed scalar)
-        int redo = 0;  // ONLY_WIDE: the waves k_multiply_ct<..., DIRECT> left out (its predicate)
-        if (ONLY_WIDE) redo = (int)(k[3] >> 63) | (int)!point_on_curve<IN_FORM>(pts, ii);
+        int redo = 0;  // ONLY_WIDE: the waves k_multiply_ct<..., DIRECT> left out, as it recorded them
+        if (ONLY_WIDE) {
+            const size_t first = round * BLOCK + (size_t)(t & ~63);
+            redo = first < n ? (int)redo_flags[first >> 6] : 0;
+        }
         if (ONLY_WIDE && !__syncthreads_or(redo)) continue;  // no such wave in this workgroup
         __syncthreads();
         recode_wnaf5_packed(k, s_naf, t);
@@ -1612,7 +1657,8 @@ template <class ACC, int IN_FORM, int OUT_FORM, bool DIRECT = false>
 __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const DeviceTables* __restrict__ tab, const u64* __restrict__ pts,
                                                             const u8* __restrict__ scalars, u64* __restrict__ out,
                                                             u8* __restrict__ inf, size_t n_groups, int m,
-                                                            u64* __restrict__ scratch, size_t words_per_block) {
+                                                            u64* __restrict__ scratch, size_t words_per_block,
+                                                            u8* __restrict__ redo_flags = nullptr /* DIRECT: one byte per wave of 64 groups */) {
     const int t = threadIdx.x;
     u64* s_tabs = scratch + (size_t)blockIdx.x * words_per_block;
     u64* s_z = s_tabs + (size_t)m * ManyScratch::TAB;
@@ -1631,13 +1677,22 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
             load_scalar(scalars, gg * m + j, k);
             recode_radix16(k, s_dig + (size_t)j * 256 * BLOCK, t);
             wide = wide || (k[3] >> 60) > 7;
-            if (DIRECT) wide = wide || !point_on_curve<IN_FORM>(pts, gg * m + j);  // off the curve: the ladders disagree
         }
-        if (DIRECT && __any(wide)) continue;  // top nibble > 7 <=> bit 255 set: this wave belongs to the NAF kernel
         const int n_entries = __any(wide) ? 16 : 8;
-        for (int j = 0; j < m; j++) {
-            s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, DIRECT>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z, s_prefix, t,
-                                                                        !DIRECT && (tab->flags & 1));
+        if (DIRECT) {
+            // top nibble > 7 <=> bit 255 set, or a point the affine table construction refuses: the wave belongs to the
+            // NAF kernel (see k_multiply_ct), recorded in redo_flags
+            bool unfit = __any(wide);
+            for (int j = 0; j < m && !unfit; j++)
+                s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, true>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z,
+                                                                          s_prefix, t, false, &unfit);
+            const size_t first = round * BLOCK + (size_t)(t & ~63);
+            if ((t & 63) == 0 && redo_flags != nullptr && first < n_groups) redo_flags[first >> 6] = unfit ? 1 : 0;
+            if (unfit) continue;
+        } else {
+            for (int j = 0; j < m; j++)
+                s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, false>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z,
+                                                                           s_prefix, t, (tab->flags & 1) != 0);
         }
         ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S
         for (int w = 63; w >= 0; w--) {
@@ -1661,7 +1716,8 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
                                                                  const u64* __restrict__ pts, const u8* __restrict__ scalars,
                                                                  u64* __restrict__ out, u8* __restrict__ inf, size_t n_groups,
                                                                  int m, int with_basepoint, u64* __restrict__ scratch,
-                                                                 size_t words_per_block) {
+                                                                 size_t words_per_block,
+                                                                 const u8* __restrict__ redo_flags = nullptr /* ONLY_WIDE, optional */) {
     const int t = threadIdx.x;
     const int ns = m + (with_basepoint ? 1 : 0);
     u64* s_tabs = scratch + (size_t)blockIdx.x * words_per_block;
@@ -1677,9 +1733,17 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_vartime(
         const bool active = g < n_groups;
         const size_t gg = active ? g : n_groups - 1;
         if (ONLY_WIDE) {
+            // the waves the fast path left out: as k_multiply_many_ct<..., DIRECT> recorded them (redo_flags), or -- for
+            // the composed a P + b G path, whose a P went through the single-scalar kernels and their own fix-up -- the
+            // waves with a scalar that has bit 255 set or a point off the curve
             int wide = 0;
-            for (int j = 0; j < ns; j++) wide |= (int)(scalars[(gg * ns + j) * 32 + 31] >> 7);
-            for (int j = 0; j < m; j++) wide |= (int)!point_on_curve<IN_FORM>(pts, gg * m + j);
+            if (redo_flags != nullptr) {
+                const size_t first = round * BLOCK + (size_t)(t & ~63);
+                wide = first < n_groups ? (int)redo_flags[first >> 6] : 0;
+            } else {
+                for (int j = 0; j < ns; j++) wide |= (int)(scalars[(gg * ns + j) * 32 + 31] >> 7);
+                for (int j = 0; j < m; j++) wide |= (int)!point_on_curve<IN_FORM>(pts, gg * m + j);
+            }
             if (!__any(wide)) continue;
         }
         for (int j = 0; j < ns; j++) {

@@ -41,7 +41,7 @@ def fuzz(budget=60.0, seed=1, max_n=1500, max_runs=None, engine=None):
 
     def scalars(n):
         sc = synth.scalars(int(rng.integers(1, 1 << 30)), n).copy()
-        special = [0, 1, 2, 15, 16, Q - 1, Q, (1 << 255) - 1, (1 << 255) + 5, (1 << 256) - 1, 1 << 255]
+        special = [0, 1, 2, 3, 7, 9, 15, 16, 0x5b, 0x99, Q - 1, Q, (1 << 255) - 1, (1 << 255) + 5, (1 << 256) - 1, 1 << 255]
         for _ in range(int(rng.integers(0, 6))):
             k = special[int(rng.integers(0, len(special)))]
             if k >= 1 << 255 and rng.random() < 0.5:
@@ -50,9 +50,25 @@ def fuzz(budget=60.0, seed=1, max_n=1500, max_runs=None, engine=None):
         return sc
 
 
+    def _low_order():
+        """points of order 2, 5 and 10 (quirk Q7: the reference's tables of the even ones are not tables of multiples)"""
+        sc = lambda x: np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).reshape(1, 32).copy()
+        xy, xinf, some = ora.affine_from_x_batch(synth.fp6_elements(60, 24))
+        cand = xy[(some == 1) & (xinf == 0)]
+        qc, _ = ora.multiply_batch(cand, 0, np.repeat(sc(Q), len(cand), axis=0), 0, vartime=True)
+        out = []
+        for d in (2, 5, 10):
+            T, tinf = ora.multiply_batch(qc, 0, np.repeat(sc(H_COFACTOR // d), len(cand), axis=0), 0, vartime=True)
+            out += [T[i].copy() for i in range(len(cand)) if tinf[i] == 0][:2]
+        return out
+
+    low_order = _low_order()
+
     def affine_points(n, off_curve=False):
         aff, _ = ora.mul_by_generator_batch(synth.scalars(int(rng.integers(1, 1 << 30)), n), 0)
         aff = aff.copy()
+        if rng.random() < 0.35:                                   # a point of small order, often alone in its wave
+            aff[int(rng.integers(0, n))] = low_order[int(rng.integers(0, len(low_order)))]
         for _ in range(int(rng.integers(0, 6))):
             i = int(rng.integers(0, n))
             c = int(rng.integers(0, 5 if off_curve else 4))

@@ -494,3 +494,101 @@ def test_point_independent_tables_return_the_same_results(eng, ora):
         assert (got == want).all() and (ginf == winf).all()
     finally:
         eng.set_point_independent_tables(False)
+
+
+def _low_order_points(ora, kats):
+    """points of order exactly 2, 5 and 10 (the cofactor is 2 * 5 * 29 * ...), from seeded points of the curve"""
+    h = 0x2150b48e071ef610049bc3f5d54304e4a
+
+    def sc(x):
+        return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).reshape(1, 32).copy()
+
+    xy, xinf, some = ora.affine_from_x_batch(synth.fp6_elements(60, 24))
+    cand = xy[(some == 1) & (xinf == 0)]
+    q_cand, _ = ora.multiply_batch(cand, 0, np.repeat(sc(synth.Q), len(cand), axis=0), 0, vartime=True)
+    low = {}
+    for d in (2, 5, 10):
+        T, tinf = ora.multiply_batch(q_cand, 0, np.repeat(sc(h // d), len(cand), axis=0), 0, vartime=True)
+        for i in range(len(cand)):
+            if tinf[i] == 0 and all(ora.multiply_batch(T[i:i + 1], 0, sc(e), 0, vartime=True)[1][0] == 0 for e in (1, 2, 5) if e < d and d % e == 0):
+                low[d] = T[i].copy()
+                break
+    assert sorted(low) == [2, 5, 10]
+    return low
+
+
+def test_low_order_points_alone_in_their_wave(eng, ora, kats):
+    """Quirk Q7 and its neighbours, each ALONE in a wave of ordinary points (so that no other lane's condition sends the
+    wave to the reference's table construction): the point of order 2 and a point of order 10, for which the reference's
+    tables are not the tables of true multiples (its complete addition meets its exceptional pair), a point of order 5,
+    the identity.  Small scalars that use each table entry in turn, every ladder and form, against the oracle.  (Found
+    in round 3: the order-10 case had gone through the affine table construction, which builds TRUE multiples.)"""
+    low = _low_order_points(ora, kats)
+    n = 384
+    base = points(eng, 91, n)
+    where = {10: IDENT, 70: low[2], 200: low[10], 300: low[5]}
+    h = 0x2150b48e071ef610049bc3f5d54304e4a
+
+    def sc(x):
+        return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).copy()
+
+    rng = np.random.default_rng(92)
+    for kk in (7, 9, 0x1f, 0x5b, 0x99, int.from_bytes(rng.bytes(31), "little")):
+        pts = base.copy()
+        k = synth.scalars(93, n).copy()
+        for i, pt in where.items():
+            pts[i] = pt
+            k[i] = sc(kk)
+        lam = synth.fp6_elements(94, n)
+        l2 = eng.fp6_square_batch(lam)
+        l3 = eng.fp6_mul_batch(l2, lam)
+        jac = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), l2), eng.fp6_mul_batch(pts[:, 6:].copy(), l3), lam], axis=1)
+        prj = np.concatenate([eng.fp6_mul_batch(pts[:, :6].copy(), lam), eng.fp6_mul_batch(pts[:, 6:].copy(), lam), lam], axis=1)
+        jac[10, 12:] = 0
+        prj[10, 12:] = 0
+        for arr, form in ((pts, AFFINE), (jac, JACOBIAN), (prj, PROJECTIVE)):
+            for out_form in sorted({AFFINE, JACOBIAN if form != PROJECTIVE else PROJECTIVE, PROJECTIVE if form != JACOBIAN else JACOBIAN}):
+                for vt in (False, True):
+                    want, winf = ora.multiply_batch(arr, form, k, out_form, vartime=vt)
+                    f = eng.multiply_vartime_batch if vt else eng.multiply_batch
+                    got, ginf = f(dev(arr), dev(k), form, out_form)
+                    bad = np.nonzero((host(got) != want).any(axis=1) | (host(ginf) != winf))[0]
+                    assert len(bad) == 0, (hex(kk), form, out_form, vt, bad[:6])
+            for out_form in (AFFINE, PROJECTIVE if form != JACOBIAN else JACOBIAN):
+                for vt in (False, True):
+                    want, winf = ora.multiply_many_batch(arr, form, k, 2, out_form, vartime=vt)
+                    f = eng.multiply_many_vartime_batch if vt else eng.multiply_many_batch
+                    got, ginf = f(dev(arr), dev(k), 2, form, out_form)
+                    bad = np.nonzero((host(got) != want).any(axis=1) | (host(ginf) != winf))[0]
+                    assert len(bad) == 0, (hex(kk), form, out_form, vt, "many", bad[:6])
+            kk2 = np.ascontiguousarray(np.stack([k, synth.scalars(95, n)], axis=1).reshape(2 * n, 32))
+            for out_form in (AFFINE, PROJECTIVE if form != JACOBIAN else JACOBIAN):
+                want, winf = ora.multiply_many_batch(arr, form, kk2, 1, out_form, vartime=True, with_basepoint=True)
+                got, ginf = eng.multiply_double_with_basepoint_vartime_batch(dev(arr), dev(kk2), form, out_form)
+                bad = np.nonzero((host(got) != want).any(axis=1) | (host(ginf) != winf))[0]
+                assert len(bad) == 0, (hex(kk), form, out_form, "a P + b G", bad[:6])
+    # the uniform-scalar ladders
+    hb = np.repeat(sc(h).reshape(1, 32), n, axis=0)
+    for out_form in (AFFINE, PROJECTIVE):
+        want, winf = ora.multiply_batch(pts, 0, hb, out_form, vartime=True)
+        got, ginf = eng.clear_cofactor_batch(dev(pts), AFFINE, out_form)
+        assert (host(got) == want).all() and (host(ginf) == winf).all(), out_form
+    want = ora.multiply_batch(pts, 0, np.repeat(sc(synth.Q).reshape(1, 32), n, axis=0), JACOBIAN, vartime=True)[1]
+    assert (host(eng.is_torsion_free_batch(dev(pts), AFFINE)) == want).all()
+    assert want[70] == 1                      # quirk Q7: the reference calls the point of order 2 torsion free
+    # BasePointTable over such a base: the reference's comb, whatever the result form
+    ks = synth.scalars(96, 200).copy()
+    ks[:, 31] &= 0x7F
+    for i in range(40):
+        ks[i] = sc(i)
+    for d in (2, 5, 10):
+        tab = ora.basepoint_table_create(low[d], AFFINE)
+        t = eng.basepoint_table(low[d].reshape(1, 12), AFFINE)
+        try:
+            for of in (AFFINE, PROJECTIVE):
+                want = ora.basepoint_table_multiply_batch(tab, ks, of)
+                got = t.multiply_batch(dev(ks), of)
+                assert (host(got[0]) == want[0]).all() and (host(got[1]) == want[1]).all(), (d, of)
+        finally:
+            t.close()
+
