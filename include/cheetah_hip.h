@@ -219,7 +219,8 @@ int32_t cheetah_basepoint_table_read(cheetah_ctx *ctx, const cheetah_basepoint_t
  * Any 32 bytes are accepted as a scalar, as in the reference.
  * Constant time, for cheetah_multiply_batch, means: no branch and no memory address in the window loops depends on a
  * digit of a canonical scalar (re-checked on the ISA of every build, tools/check_ct_isa.py).  It does NOT mean
- * independence of the POINTS: a wave that holds the identity, a point of order <= 16 or a point that is not on the
+ * independence of the POINTS: a wave that holds the identity, a point of order <= 16 (or one with the point of order 2
+ * among its first 16 multiples: orders 2 and 10) or a point that is not on the
  * curve rebuilds its window tables with the reference's complete additions (src/lookup.rs:25-37) instead of the
  * shared-inversion affine steps, and a wave that holds a scalar with the top nibble > 7 (no canonical scalar) builds
  * 16 table entries instead of 8.  The reference's LookupTable::from has neither branch;
