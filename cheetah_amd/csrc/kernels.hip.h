@@ -1079,16 +1079,12 @@ CH_DEV bool build_table_affine(const Affine& P, int n_entries, u64* s_tab, u64* 
 
 // LookupTable<N>::from for the lane's input point: the shared-inversion affine construction, and for a wave that holds
 // an exceptional point the reference's own construction.  Returns the identity mask of the entries.
-// NAF_IDENTITY (the vartime entry points' fixed-window fast path): a ProjectivePoint (X, Y, 0) with X != 0 is an
-// identity to the reference (is_identity() is z == 0, and its unchecked formulas do return such representatives), but
-// it is not a point of the curve, so the complete additions that fill LookupTable<N> turn its "multiples" into
-// arbitrary values: the reference's multiply() really returns those (and so does the constant-time path here), while
-// its multiply_vartime() returns the identity -- every entry of its NafLookupTable stays at z = 0.  With NAF_IDENTITY
-// such an input is replaced by (0, 1, 0), whose table is all identities, so the fast path agrees with the NAF ladder.
 // wave_unfit (the vartime fast paths): set instead of rebuilding when the wave holds a point the affine construction
-// refuses -- for such a point the reference's multiply_vartime is its NAF ladder over its NafLookupTable, which no
-// LookupTable reproduces, so the caller leaves the wave to the NAF kernel.
-template <int IN_FORM, bool NAF_IDENTITY = false>
+// refuses (the identity in any encoding, small order, quirk Q7, off the curve) -- for such a point the reference's
+// multiply_vartime is its NAF ladder over its NafLookupTable, which no LookupTable reproduces (a ProjectivePoint
+// (X, Y, 0) with X != 0, for one, is multiplied into arbitrary values by multiply() and into the identity by
+// multiply_vartime()), so the caller leaves the wave to the NAF kernel.
+template <int IN_FORM>
 CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_tab, u64* s_z, u64* s_prefix, int t,
                               bool reference_only = false, bool* wave_unfit = nullptr) {
     Affine pa;
@@ -1114,9 +1110,7 @@ CH_DEV u32 build_lookup_table(const u64* pts, size_t i, int n_entries, u64* s_ta
             *wave_unfit = true;
             return 0u;
         }
-        Proj p = load_input_point<IN_FORM>(pts, i);
-        if (IN_FORM == 1 && NAF_IDENTITY && fp6_is_zero(p.z)) p = proj_identity();
-        return build_table<false>(p, n_entries, s_tab, s_z, s_prefix, t);
+        return build_table<false>(load_input_point<IN_FORM>(pts, i), n_entries, s_tab, s_z, s_prefix, t);
     }
     return 0u;
 }
@@ -1293,12 +1287,12 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_multiply_ct(const Device
             // k_multiply_vartime<..., ONLY_WIDE> reads.
             bool unfit = __any((int)(k[3] >> 63));
             ident = 0;
-            if (!unfit) ident = build_lookup_table<IN_FORM, true>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, false, &unfit);
+            if (!unfit) ident = build_lookup_table<IN_FORM>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, false, &unfit);
             const size_t first = round * BLOCK + (size_t)(t & ~63);  // the wave's first item
             if ((t & 63) == 0 && redo_flags != nullptr && first < n) redo_flags[first >> 6] = unfit ? 1 : 0;
             if (unfit) continue;
         } else {
-            ident = build_lookup_table<IN_FORM, false>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, (tab->flags & 1) != 0);
+            ident = build_lookup_table<IN_FORM>(pts, ii, n_entries, s_tab, s_z, s_prefix, t, (tab->flags & 1) != 0);
         }
         const ACC acc = ladder_radix16<ACC, DIRECT>(tab, s_tab, n_entries, ident, s_digits, t, mshift);
         if (active) emit_point<OUT_FORM>(out, inf, i, acc);
@@ -1684,14 +1678,14 @@ __global__ void __launch_bounds__(BLOCK, CH_MANY_WAVES) k_multiply_many_ct(const
             // NAF kernel (see k_multiply_ct), recorded in redo_flags
             bool unfit = __any(wide);
             for (int j = 0; j < m && !unfit; j++)
-                s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, true>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z,
+                s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z,
                                                                           s_prefix, t, false, &unfit);
             const size_t first = round * BLOCK + (size_t)(t & ~63);
             if ((t & 63) == 0 && redo_flags != nullptr && first < n_groups) redo_flags[first >> 6] = unfit ? 1 : 0;
             if (unfit) continue;
         } else {
             for (int j = 0; j < m; j++)
-                s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM, false>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z,
+                s_ident[j * BLOCK + t] = build_lookup_table<IN_FORM>(pts, gg * m + j, n_entries, s_tabs + (size_t)j * ManyScratch::TAB, s_z,
                                                                            s_prefix, t, (tab->flags & 1) != 0);
         }
         ACC acc = Ladder<ACC>::shift16(tab);  // window 63's four doublings of S

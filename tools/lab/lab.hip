@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_lab_multiply_w5(const De
         __syncthreads();
         recode_radix32(k, s_digits, t);
         __syncthreads();
-        const u32 ident = build_lookup_table<0, DIRECT>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_lookup_table<0>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
         int d = s_digits[51 * BLOCK + t];
         MJac acc = Ladder<MJac>::add(shift32, DIRECT ? index_lookup(s_tab, ident, d, t) : scan_lookup(s_tab, n_entries, ident, d, t));
         for (int j = 50; j >= 0; j--) {
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(BLOCK, CH_CT_WAVES) k_lab_multiply_w4_minus2s(
         __syncthreads();
         recode_radix16(k, s_digits, t);
         __syncthreads();
-        const u32 ident = build_lookup_table<0, false>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
+        const u32 ident = build_lookup_table<0>(pts, ii, n_entries, s_tab, s_z, s_prefix, t);
         int d = s_digits[63 * BLOCK + t];
         MJac acc = Ladder<MJac>::add(Ladder<MJac>::shift16(tab), scan_lookup(s_tab, n_entries, ident, d, t));
         for (int j = 62; j >= 0; j--) {
