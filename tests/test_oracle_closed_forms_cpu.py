@@ -442,3 +442,32 @@ def test_quirk_the_complete_formulas_are_not_complete_on_this_curve(ora):
         assert inf[0] == (1 if want[2] == M.ZERO else 0)
     got, inf = ora.multiply_batch(t2, AFFINE, sc(3), JACOBIAN, vartime=True)
     assert inf[0] == 1                                                   # "3 T = O"
+    # a point of order 10: 5 P is the point of order 2, so the chain (i + 1) P = P + i P of LookupTable::from meets the
+    # exceptional pair at 7 P = P + 6 P (their difference is 5 P) and everything after it is (0, 0, 0) too; the chain
+    # (2i + 1) P = 2 P + (2i - 1) P of NafLookupTable::from meets it at 9 P = 2 P + 7 P
+    from cheetah_amd import synth
+    xy, xinf, some = ora.affine_from_x_batch(synth.fp6_elements(60, 24))         # seeded points of the curve
+    cand = xy[(some == 1) & (xinf == 0)]
+    qc, _ = ora.multiply_batch(cand, AFFINE, np.repeat(sc(M.Q), len(cand), axis=0), AFFINE, vartime=True)
+    t10s, tinfs = ora.multiply_batch(qc, AFFINE, np.repeat(sc(h // 10), len(cand), axis=0), AFFINE, vartime=True)
+    t10 = None
+    for i in range(len(cand)):
+        P10 = (_t(t10s[i, :6]), _t(t10s[i, 6:]))
+        if tinfs[i] == 0 and M.scalar_mul(5, P10) is not None and M.scalar_mul(2, P10) is not None:
+            t10 = t10s[i:i + 1]
+            break
+    assert t10 is not None, "no point of order exactly 10 among the candidates"
+    if True:
+        assert M.scalar_mul(10, P10) is None and M.scalar_mul(5, P10)[1] == M.ZERO
+        six = M.scalar_mul(6, P10)
+        assert rcb_add((P10[0], P10[1], M.ONE), (six[0], six[1], M.ONE)) == (M.ZERO, M.ZERO, M.ZERO)
+        ct_table = lambda j: M.scalar_mul(j, P10) if j <= 6 else None
+        naf_table = lambda j: M.scalar_mul(j, P10) if j <= 7 else None
+        for k in (6, 7, 9, 0x77, 0x99, 0xabcdef, M.Q):
+            for vt, table in ((False, ct_table), (True, naf_table)):
+                want = _ladder(P10, k, vt, hehcc_double, jac_add_mixed, entry_fn=table)
+                got, inf = ora.multiply_batch(t10, AFFINE, sc(k), JACOBIAN, vartime=vt)
+                assert [_t(got[0, :6]), _t(got[0, 6:12]), _t(got[0, 12:])] == [want[0], want[1], want[2]], (k, vt)
+        assert ora.multiply_batch(t10, AFFINE, sc(7), AFFINE, vartime=False)[1][0] == 1      # "7 P = O" by multiply()
+        assert ora.multiply_batch(t10, AFFINE, sc(7), AFFINE, vartime=True)[1][0] == 0       # but not by multiply_vartime()
+
