@@ -208,6 +208,10 @@ static int32_t create_one(int device_id, int shard_index, cheetah_ctx** out) {
     const int waves = CH_CT_WAVES > CH_VT_WAVES ? CH_CT_WAVES : CH_VT_WAVES;
     ctx->scratch_words = (size_t)ctx->num_cus * waves * LaneScratch::WORDS_PER_BLOCK;
     CREATE_TRY(hipMalloc(&ctx->scratch, ctx->scratch_words * sizeof(u64)));
+    // one byte per wave of the largest launch (256 rounds of 1 024 workgroups): the vartime fast paths' verdicts; allocated
+    // here so that no _dev call has to
+    ctx->redo_flags.bytes = ((size_t)1 << 20) + 64;
+    CREATE_TRY(hipMalloc(&ctx->redo_flags.p, ctx->redo_flags.bytes));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
 #undef CREATE_TRY
     *out = ctx;
@@ -1190,7 +1194,7 @@ static int32_t multiply_impl(cheetah_ctx* ctx, const u64* pts, int in_form, cons
     const size_t per_launch = (size_t)grid * BLOCK * ctx->launch_rounds * (pooled ? VtPool::SLOTS * POOL_ROUNDS_FACTOR : 1);
     u8* flags = nullptr;  // the fast path's verdict per wave of a launch, read by the NAF kernel that follows it
     if (direct) {
-        if (int32_t rc = ensure_slot(ctx, ctx->redo_flags, ((size_t)1 << 16) > per_launch / 64 + 1 ? ((size_t)1 << 16) : per_launch / 64 + 1, ctx->stream)) return rc;
+        if (int32_t rc = ensure_slot(ctx, ctx->redo_flags, per_launch / 64 + 1, ctx->stream)) return rc;
         flags = static_cast<u8*>(ctx->redo_flags.p);
     }
     for (size_t off = 0; off < n; off += per_launch) {
@@ -1340,7 +1344,7 @@ static int32_t multiply_many_impl(cheetah_ctx* ctx, const u64* pts, int in_form,
     const size_t per_launch = (size_t)grid * BLOCK * rounds;
     u8* flags = nullptr;
     if (VARTIME && out_form == CHEETAH_AFFINE && !with_basepoint && !ctx->force_reference_schedule) {
-        if (int32_t rc = ensure_slot(ctx, ctx->redo_flags, ((size_t)1 << 16) > per_launch / 64 + 1 ? ((size_t)1 << 16) : per_launch / 64 + 1, ctx->stream)) return rc;
+        if (int32_t rc = ensure_slot(ctx, ctx->redo_flags, per_launch / 64 + 1, ctx->stream)) return rc;
         flags = static_cast<u8*>(ctx->redo_flags.p);
     }
     for (size_t off = 0; off < n_groups; off += per_launch) {
