@@ -471,3 +471,68 @@ def test_quirk_the_complete_formulas_are_not_complete_on_this_curve(ora):
         assert ora.multiply_batch(t10, AFFINE, sc(7), AFFINE, vartime=False)[1][0] == 1      # "7 P = O" by multiply()
         assert ora.multiply_batch(t10, AFFINE, sc(7), AFFINE, vartime=True)[1][0] == 0       # but not by multiply_vartime()
 
+
+
+def test_special_case_selections_and_batch_normalize_from_the_model(ora):
+    """What the closed forms do not decide: the selections around them, stated here from the reference's text and
+    evaluated with the model.  JacobianPoint::add (src/curve/jacobian.rs:452-505) returns, in this order of precedence
+    (each later selection overrides the earlier ones): the chord formula; rhs if self is the identity; self if rhs is;
+    JacobianPoint::identity() = (1, 1, 0) if rhs == -self; self.double() if rhs == self -- equality being ct_eq on
+    cross-multiplied coordinates, so on other representatives of the same point too.  add_mixed (:508-552) has no
+    selection for "self is the identity" (quirk Q6: the chord formula's z3 = z e = 0 stands).  batch_normalize
+    (:886-920) divides by z^2, z^3 and returns AffinePoint::identity() = (0, 1, infinity) for z = 0 (SURVEY Q5)."""
+    rng = np.random.default_rng(21)
+    g = ora.table("ora_generator_affine", 1)[0]
+    G = (_t(g[:6]), _t(g[6:]))
+
+    def jac(pt, z):                      # (x z^2, y z^3, z)
+        return (_mul(pt[0], z, z), _mul(pt[1], z, z, z), z)
+
+    def row(p):
+        return list(p[0]) + list(p[1]) + list(p[2])
+
+    P = M.scalar_mul(int(rng.integers(2, 2**60)), G)
+    R = M.scalar_mul(int(rng.integers(2, 2**60)), G)
+    z1, z2 = _t(rng.integers(1, M.P, 6, dtype=np.uint64)), _t(rng.integers(1, M.P, 6, dtype=np.uint64))
+    ident = ((5, 0, 0, 0, 0, 0), (9, 0, 0, 0, 0, 0), M.ZERO)          # some identity: z = 0
+    negP = (P[0], M.f6_neg(P[1]))
+    cases = [
+        ("chord", jac(P, z1), jac(R, z2), hehcc_add(jac(P, z1), jac(R, z2))),
+        ("self identity", ident, jac(R, z2), jac(R, z2)),
+        ("rhs identity", jac(P, z1), ident, jac(P, z1)),
+        ("both identities", ident, ident, (M.ONE, M.ONE, M.ZERO)),   # ct_eq calls two identities equal: identity(), then its double()
+        ("rhs == -self, other representative", jac(P, z1), jac(negP, z2), (M.ONE, M.ONE, M.ZERO)),
+        ("rhs == self, other representative", jac(P, z1), jac(P, z2), hehcc_double(jac(P, z1))),
+    ]
+    lhs = np.array([row(c[1]) for c in cases], np.uint64)
+    rhs = np.array([row(c[2]) for c in cases], np.uint64)
+    got = ora.add_batch(lhs, JACOBIAN, rhs, JACOBIAN)
+    for i, c in enumerate(cases):
+        assert [_t(got[i, :6]), _t(got[i, 6:12]), _t(got[i, 12:])] == [M.f6(c[3][0]), M.f6(c[3][1]), M.f6(c[3][2])], c[0]
+    # add_mixed: an affine rhs, (0, 1) its identity
+    mixed = [
+        ("chord", jac(P, z1), R, hehcc_add(jac(P, z1), (R[0], R[1], M.ONE))),
+        ("rhs identity", jac(P, z1), (M.ZERO, M.ONE), jac(P, z1)),
+        ("rhs == -self", jac(P, z1), negP, (M.ONE, M.ONE, M.ZERO)),
+        ("rhs == self", jac(P, z1), P, hehcc_double(jac(P, z1))),
+        ("self identity: quirk Q6", ident, R, hehcc_add(ident, (R[0], R[1], M.ONE))),
+    ]
+    lhs = np.array([row(c[1]) for c in mixed], np.uint64)
+    rhs = np.array([list(c[2][0]) + list(c[2][1]) for c in mixed], np.uint64)
+    got = ora.add_batch(lhs, JACOBIAN, rhs, AFFINE)
+    for i, c in enumerate(mixed):
+        assert [_t(got[i, :6]), _t(got[i, 6:12]), _t(got[i, 12:])] == [M.f6(c[3][0]), M.f6(c[3][1]), M.f6(c[3][2])], c[0]
+    assert _t(got[4, 12:]) == M.ZERO                                 # Q6: O + R comes out as an identity
+    # batch_normalize
+    pts = [jac(P, z1), ident, jac(R, z2), jac(P, z2), ((1, 2, 3, 4, 5, 6), (7, 8, 9, 10, 11, 12), M.ZERO)]
+    xy, inf = ora.batch_normalize(np.array([row(p) for p in pts], np.uint64), True)
+    want = [P, None, R, P, None]
+    for i, w in enumerate(want):
+        if w is None:
+            assert inf[i] == 1 and _t(xy[i, :6]) == M.ZERO and _t(xy[i, 6:]) == M.ONE
+        else:
+            assert inf[i] == 0 and _t(xy[i, :6]) == w[0] and _t(xy[i, 6:]) == w[1]
+    prj = [(_mul(P[0], z1), _mul(P[1], z1), z1), ((3, 0, 0, 0, 0, 0), (4, 0, 0, 0, 0, 0), M.ZERO), (_mul(R[0], z2), _mul(R[1], z2), z2)]
+    xy, inf = ora.batch_normalize(np.array([row(p) for p in prj], np.uint64), False)
+    assert inf.tolist() == [0, 1, 0] and _t(xy[0, :6]) == P[0] and _t(xy[0, 6:]) == P[1] and _t(xy[2, :6]) == R[0] and _t(xy[2, 6:]) == R[1]
+    assert _t(xy[1, :6]) == M.ZERO and _t(xy[1, 6:]) == M.ONE
