@@ -536,3 +536,60 @@ def test_special_case_selections_and_batch_normalize_from_the_model(ora):
     xy, inf = ora.batch_normalize(np.array([row(p) for p in prj], np.uint64), False)
     assert inf.tolist() == [0, 1, 0] and _t(xy[0, :6]) == P[0] and _t(xy[0, 6:]) == P[1] and _t(xy[2, :6]) == R[0] and _t(xy[2, 6:]) == R[1]
     assert _t(xy[1, :6]) == M.ZERO and _t(xy[1, 6:]) == M.ONE
+
+
+def test_recoders_against_their_arithmetic_definitions(ora):
+    """The scalar recoders restated as integer arithmetic (no words, windows or carries) against the oracle's
+    restatement of the reference's word-level code (src/scalar.rs:531-643), any 32 bytes, scalars >= 2^255 included:
+      radix 16 / 256: digits by repeated centred division, the top digit left as it comes;
+      width-w NAF (Hankerson-Menezes-Vanstone Alg. 3.35): while k != 0: if k is odd, the digit is k mods 2^w and is
+      subtracted; halve -- cut off after 256 digits (the reference's array is [i8; 256]: for k >= 2^255 the last carry
+      falls off the end, which is why the vartime fast paths leave such scalars to the NAF kernels)."""
+    lib = ora.lib()
+    rng = np.random.default_rng(31)
+    ks = [0, 1, 15, 16, 2**255 - 1, 2**255, 2**256 - 1, M.Q, M.Q - 1, 0x8000000000000000 << 192]
+    ks += [int.from_bytes(rng.bytes(32), "little") for _ in range(300)]
+    ks += [int.from_bytes(rng.bytes(32), "little") | (1 << 255) for _ in range(100)]
+
+    def centred(k, bits, n):
+        d = []
+        for i in range(n):
+            if i == n - 1:
+                d.append(k)                                   # whatever is left
+                break
+            r = k & ((1 << bits) - 1)
+            if r >= 1 << (bits - 1):
+                r -= 1 << bits
+            d.append(r)
+            k = (k - r) >> bits
+        return d
+
+    def wnaf(k, w):
+        d = []
+        while len(d) < 256:
+            z = 0
+            if k & 1:
+                z = k & ((1 << w) - 1)
+                if z >= 1 << (w - 1):
+                    z -= 1 << w
+                k -= z
+            d.append(z)
+            k >>= 1
+        return d
+
+    for k in ks:
+        b = np.frombuffer(k.to_bytes(32, "little"), np.uint8).copy()
+        o16, o256, o5, o8 = np.zeros(64, np.int8), np.zeros(32, np.int8), np.zeros(256, np.int8), np.zeros(256, np.int8)
+        lib.ora_bytes_to_radix_16(b, o16)
+        lib.ora_bytes_to_radix_256(b, o256)
+        lib.ora_bytes_to_wnaf_vartime(b, 5, o5)
+        lib.ora_bytes_to_wnaf_vartime(b, 8, o8)
+        assert o16.tolist() == centred(k, 4, 64), hex(k)
+        want256 = centred(k, 8, 32)
+        want256[31] = ((want256[31] + 128) % 256) - 128       # the reference narrows its i16 digits to i8
+        assert o256.tolist() == want256, hex(k)
+        assert o5.tolist() == wnaf(k, 5), hex(k)
+        w8 = [((z + 128) % 256) - 128 for z in wnaf(k, 8)]
+        assert o8.tolist() == w8, hex(k)
+        if k < 1 << 255:
+            assert sum(int(z) << i for i, z in enumerate(o5)) == k and sum(int(z) << i for i, z in enumerate(o8)) == k
